@@ -1,0 +1,303 @@
+"""Regenerates tests/golden/*.npz by RUNNING THE REFERENCE (read-only at /root/reference).
+
+Run only in the build container:   python tests/golden/make_golden.py [section ...]
+The GPU box has no /root/reference; tests there use the committed .npz files.
+
+The fixtures hold OUTPUTS of the reference (and the few random draws it made); inputs and weights
+are regenerated from (seed, shape) by the package's `synthetic` module, so nothing of the reference
+(source, weights it shipped, data) is stored.  Absent third-party packages that the hot path never
+calls are replaced by empty stub modules in sys.modules; no reference file
+is modified or copied.
+"""
+import importlib
+import importlib.util
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+pkg = importlib.import_module("3d-semantic-segmentation-amp-net_amd")
+synth = importlib.import_module("3d-semantic-segmentation-amp-net_amd.synthetic")
+P = importlib.import_module("3d-semantic-segmentation-amp-net_amd.params")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, n):
+            return lambda *a, **k: None
+
+    _stub("pointNet_2")
+    _stub("pointNet_2.models")
+    _stub("pointNet_2.models.pointnet2_utils", PointNetSetAbstraction=_Dummy, PointNetFeaturePropagation=_Dummy)
+    _stub("k_means_constrained", KMeansConstrained=_Dummy)
+    _stub("progressbar", progressbar=lambda x, *a, **k: x)
+    _stub("laspy")
+    _stub("prettytable", PrettyTable=_Dummy)
+    if "torch.utils.tensorboard" not in sys.modules:
+        try:
+            import torch.utils.tensorboard  # noqa: F401
+        except Exception:
+            _stub("torch.utils.tensorboard", SummaryWriter=_Dummy)
+
+
+def load_script(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = [path]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def ref_models(enc_seed, head_seed, dropout=0.3):
+    from pointNet.model.pointnetAtt import BasePointNet, SegmentationWithAttention
+    enc = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device="cpu")
+    att = SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, dropout=dropout, device="cpu")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(enc_seed, P.ENC_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(enc_seed, P.ENC_BUFFERS).items()})
+    missing = enc.load_state_dict(sd, strict=False)
+    assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(head_seed, P.HEAD_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(head_seed, P.HEAD_BUFFERS).items()})
+    missing = att.load_state_dict(sd, strict=False)
+    assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys
+    return enc, att
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------
+def sec_fps():
+    """a1: utils/utils.py:889-933.  The reference returns rows, not indices: column 3 carries the row id."""
+    from utils.utils import fps
+    out = {}
+    cases = [("small", 11, 1000, 100), ("dup", 12, 512, 300), ("c5", 13, 8192, 4096), ("tiny", 14, 64, 64)]
+    for name, seed, n, s in cases:
+        xyz = synth.clouds(seed, 1, n)[0]
+        if name == "dup":
+            xyz[n // 2:] = xyz[: n // 2]            # every point twice -> distance ties and zeros
+        pc = np.concatenate([xyz, np.arange(n, dtype=np.float32)[:, None]], axis=1)
+        got = fps(pc, s)
+        out[f"{name}_meta"] = np.array([seed, n, s], dtype=np.int64)
+        out[f"{name}_idx"] = got[:, 3].astype(np.int64)
+    save("fps", **out)
+
+
+def sec_encoder():
+    """a2/a3: pointnetAtt.py:28-47, 80-112 -- eval forward and one train-mode forward."""
+    enc, _ = ref_models(1, 2)
+    x = torch.from_numpy(synth.windows(21, 2, 256))
+    enc.eval()
+    with torch.no_grad():
+        out, ft = enc(x)
+        t_in = enc.input_transform(x[:, :, :3])
+    res = dict(eval_local=out[:, :, -64:], eval_global=out[:, 0, :-64], eval_feat_T=ft, eval_in_T=t_in)
+    # train mode: batch statistics + running-stat update
+    xt = torch.from_numpy(synth.windows(22, 4, 128))
+    enc.train()
+    with torch.no_grad():
+        out, ft = enc(xt)
+    res.update(train_local=out[:, :, -64:], train_global=out[:, 0, :-64], train_feat_T=ft)
+    sd = enc.state_dict()
+    for k in ["bn_1.running_mean", "bn_1.running_var", "bn_6.running_var", "input_transform.bn_4.running_mean",
+              "input_transform.bn_4.running_var", "feature_transform.bn_3.running_var",
+              "feature_transform.bn_5.running_mean", "bn_6.num_batches_tracked"]:
+        res["train_" + k] = sd[k]
+    save("encoder", **res)
+
+
+def sec_head():
+    """a4: pointnetAtt.py:176-209 eval forward: uniform clusters with one padded cluster, ragged clusters, no mask."""
+    _, att = ref_models(1, 2)
+    att.eval()
+    gl = torch.from_numpy(synth.uniform(31, (3, 2, 256), 0.0, 2.0))
+    lo = torch.from_numpy(synth.uniform(32, (2, 768, 64), -1.0, 1.0))
+    cent = torch.from_numpy(synth.uniform(33, (2, 3, 2), -1.0, 1.0))
+    mask = torch.tensor([[False, False, True], [False, False, False]])
+    with torch.no_grad():
+        a, _ = att(gl, lo, cent, [256, 256, 256], mask)
+        b, _ = att(gl, lo, cent, [100, 300, 368], None)
+    save("head", uniform_masked=a, ragged_nomask=b)
+
+
+# B = 16: the T-Net FC BatchNorms normalise over the B rows of one window slot; with B = 3 the reference's own
+# fp32 gradients sit 4 % from an fp64 evaluation of the same graph (ill-conditioned), useless as a pin.
+STEP_B, STEP_N, STEP_W = 16, 64, 3
+STEP_WREAL = [3, 2, 3, 1, 2, 3, 3, 2, 1, 3, 2, 3, 3, 1, 2, 3]
+
+
+def sec_step():
+    """a5/a6/a7: train_pointnet-attention.py:337-475 train_loop itself, train=False then train=True twice.
+
+    Dropout is constructed with p=0 (a constructor argument of the reference head, pointnetAtt.py:155) so
+    that the train-mode step is deterministic; the numpy RNG the augmentations draw from is seeded and the
+    draws are recorded (cluster permutation, angle, point permutations)."""
+    tr = load_script(os.path.join(REF, "pointNet/self-attention/train_pointnet-attention.py"), "ref_train_att")
+    enc, att = ref_models(3, 4, dropout=0.0)
+    B, N, W = STEP_B, STEP_N, STEP_W
+    pc, tg, cent, w_real = synth.sample_batch(41, B, N, max_w=W, w_real=STEP_WREAL)
+    names = [f"f{i}" for i in range(B)]
+    data = (torch.from_numpy(pc), torch.from_numpy(tg), names, torch.from_numpy(cent))
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
+    opt_p = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    opt_a = torch.optim.Adam(att.parameters(), lr=1e-3)
+    res = dict(meta=np.array([B, N, W], dtype=np.int64), w_real=w_real)
+
+    np.random.seed(777)
+    with torch.no_grad():
+        m, tpc, preds, _ = tr.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", False, 0, 0)
+    res.update(eval_ce=m["ce_loss"].detach().numpy(), eval_reg=m["reg_loss"].detach().numpy(),
+               eval_loss=m["loss"].detach().numpy(), eval_targets=tpc.numpy(), eval_preds=preds.numpy())
+
+    for step in (1, 2):
+        np.random.seed(1000 + step)
+        data = (torch.from_numpy(pc.copy()), torch.from_numpy(tg.copy()), names, torch.from_numpy(cent))
+        m, tpc, preds, _ = tr.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+        res[f"s{step}_ce"] = m["ce_loss"].detach().numpy()
+        res[f"s{step}_reg"] = m["reg_loss"].detach().numpy()
+        res[f"s{step}_loss"] = m["loss"].detach().numpy()
+        res[f"s{step}_preds"] = preds.numpy()
+        res[f"s{step}_targets"] = tpc.numpy()
+        for tag, mod in (("enc", enc), ("att", att)):
+            for k, p in mod.named_parameters():
+                g = p.grad.detach().double()
+                res[f"s{step}_{tag}_gnorm/{k}"] = np.array([g.norm().item(), g.sum().item()])
+                if p.numel() <= 4096:
+                    res[f"s{step}_{tag}_grad/{k}"] = p.grad.detach().numpy()
+                res[f"s{step}_{tag}_psum/{k}"] = np.array([p.detach().double().sum().item(),
+                                                           p.detach().double().abs().sum().item()])
+    for tag, mod in (("enc", enc), ("att", att)):
+        for k, v in mod.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                res[f"final_{tag}_buf/{k}"] = v.numpy()
+    # small parameters in full after two Adam steps
+    for k in ["input_transform.fc_3.bias", "bn_6.weight", "conv_1.weight"]:
+        res[f"final_enc_param/{k}"] = enc.state_dict()[k].numpy()
+    for k in ["conv_4.weight", "fc1.weight", "attention.out_proj.bias"]:
+        res[f"final_att_param/{k}"] = att.state_dict()[k].numpy()
+    save("step", **res)
+
+
+def sec_metrics():
+    """a11: utils/get_metrics.py:6-31, utils/utils.py:14-19."""
+    from utils.get_metrics import get_iou_obj, get_accuracy
+    from utils.utils import rm_padding
+    preds = torch.from_numpy(synth.randint(51, (4000,), 0, 5))
+    tgt = synth.randint(52, (4000,), 0, 5)
+    tgt[synth.uniform01(53, (4000,)) < 0.2] = -1
+    tgt = torch.from_numpy(tgt)
+    p2, t2, keep = rm_padding(preds, tgt)
+    ious = [get_iou_obj(p2, t2, c) for c in range(5)]
+    acc = get_accuracy(p2, t2, {}, "segmentation", None)["accuracy"]
+    # a class absent from both preds and targets -> nan
+    p3 = torch.tensor([0, 0, 1, 1]); t3 = torch.tensor([0, 1, 1, 1])
+    with np.errstate(all="ignore"):
+        absent = get_iou_obj(p3, t3, 4)
+    save("metrics", ious=np.array(ious), acc=np.array(acc), n_keep=np.array(int(keep.sum())), absent=np.array(absent))
+
+
+def sec_collate():
+    """a9: pointNet/collate_fns.py:4-55 with the python/torch RNGs seeded."""
+    from pointNet.collate_fns import collate_seq_padd
+    res = {}
+    specs = [(61, 2048, 1), (62, 2048, 3), (63, 1500, 5), (64, 3000, 9), (65, 2048, 9)]
+    batch = []
+    for seed, n, w in specs:
+        win = synth.windows(seed, w, n)                               # [w, n, 9]
+        pc = np.ascontiguousarray(win.transpose(1, 2, 0))             # [n, 9, w]
+        lab = synth.labels_for(win, seed).transpose(1, 0).copy()     # [n, w]
+        cent = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], 0).astype(np.float32)   # [2, w]
+        batch.append((pc, lab, f"f{seed}", cent))
+    random.seed(5); torch.manual_seed(5)
+    data, tg, names, cents = collate_seq_padd(batch)
+    res["data_shape"] = np.array(data.shape); res["tg_shape"] = np.array(tg.shape)
+    res["cents"] = cents.numpy()
+    res["data_sum"] = data.double().sum(dim=(1, 2)).numpy()          # [B, 9] per-cluster sums
+    res["data_probe"] = data[:, ::97, :, :].numpy()
+    res["tg_probe"] = tg[:, ::97, :].numpy()
+    res["tg_sum"] = tg.sum(dim=1).numpy()
+    save("collate", **res)
+
+
+def sec_dataset():
+    """a10: pointNet/datasets.py:295-460 LidarKmeansDataset on a synthetic kmeans_<name>.pt."""
+    import tempfile
+    from pointNet.datasets import LidarKmeansDataset
+    ds_mod = importlib.import_module("3d-semantic-segmentation-amp-net_amd.synthetic")
+    with tempfile.TemporaryDirectory() as d:
+        raw = ds_mod.kmeans_file_tensor(71, 96, 3)
+        torch.save(torch.from_numpy(raw), os.path.join(d, "kmeans_tile71.pt"))
+        ds = LidarKmeansDataset(d, task="segmentation", number_of_points=2048, files=["tile71.pt"],
+                                fixed_num_points=True, c_sample=False, sort_kmeans=False, get_centroids=True)
+        pc, lab, fn, cent = ds[0]
+    save("dataset", pc=np.asarray(pc), labels=lab.numpy(), centroids=np.asarray(cent))
+
+
+def sec_baseline():
+    """a12 / config 1: pointNet/model/pointnet.py:128-154 SegmentationPointNet(5, point_dimension=3), eval, [4,512,9]."""
+    from pointNet.model.pointnet import SegmentationPointNet
+    torch.manual_seed(0)
+    net = SegmentationPointNet(num_classes=5, point_dimension=3)
+    table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+    sd = {}
+    for i, (k, shp) in enumerate(table.items()):
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, -0.3, 0.3))
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, 0.5, 1.5))
+        elif ".bn" in k or k.startswith("bn"):
+            lo, hi = (0.5, 1.5) if k.endswith("weight") else (-0.2, 0.2)
+            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, lo, hi))
+        else:
+            fan = int(np.prod(shp[1:])) if len(shp) > 1 else int(shp[0])
+            b = 1.0 / np.sqrt(fan)
+            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, -b, b))
+    net.load_state_dict(sd, strict=False)
+    net.eval()
+    x = torch.from_numpy(synth.windows(81, 4, 512))
+    with torch.no_grad():
+        logits, ft = net(x)
+    names = np.array(list(table.keys()))
+    shapes = np.array([";".join(map(str, s)) for s in table.values()])
+    save("baseline", logits=logits.numpy(), feat_T=ft.numpy(), names=names, shapes=shapes)
+
+
+SECTIONS = dict(fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
+                collate=sec_collate, dataset=sec_dataset, baseline=sec_baseline)
+
+if __name__ == "__main__":
+    install_stubs()
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        print("==", s)
+        SECTIONS[s]()

@@ -1,0 +1,32 @@
+"""Shared test helpers (host side only)."""
+import numpy as np
+import torch
+
+
+def torch_params(d):
+    return {k: torch.from_numpy(np.array(v, copy=True)) for k, v in d.items()}
+
+
+def replay_augment(seed, pc, tg, train):
+    """Replays the numpy draws of the reference's train_loop in order
+    (train_pointnet-attention.py:390-405 with utils/utils.py:582-632): cluster permutation, angle,
+    then per window: z-rotation of xyz (float64 product rounded to float32) and one point permutation.
+    pc [B,N,9,W] f32, tg [B,N,W] i64 -> augmented copies."""
+    np.random.seed(seed)
+    W = pc.shape[3]
+    idx = np.arange(W)
+    np.random.shuffle(idx)
+    pc = pc[:, :, :, idx].copy()
+    tg = tg[:, :, idx].copy()
+    angle = np.random.uniform() * 2 * np.pi
+    if train:
+        c, s = np.cos(angle), np.sin(angle)
+        rot = np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]])
+        for w in range(W):
+            xyz = pc[:, :, :3, w]
+            pc[:, :, :3, w] = np.dot(xyz.reshape(-1, 3), rot).reshape(xyz.shape).astype(np.float32)
+            pidx = np.arange(pc.shape[1])
+            np.random.shuffle(pidx)
+            pc[:, :, :, w] = pc[:, :, :, w][:, pidx, :]
+            tg[:, :, w] = tg[:, :, w][:, pidx]
+    return pc, tg
