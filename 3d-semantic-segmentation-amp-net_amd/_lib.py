@@ -1,0 +1,82 @@
+"""ctypes binding of libampnet_hip.so (include/ampnet_hip.h).
+
+There is no CPU fallback: if the library is missing, fails to load, or reports an error, the caller
+gets an exception.  torch is imported first so that the HIP runtime torch already mapped
+(its bundled libamdhip64, SONAME libamdhip64.so.7) is the one this library binds to -- two HIP runtimes in
+one process would not share device pointers.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libampnet_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class AmpnetError(RuntimeError):
+    pass
+
+
+def _hip_runtimes_mapped():
+    seen = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    seen.add(line.split()[-1])
+    except OSError:
+        pass
+    return seen
+
+
+def lib():
+    """The loaded library (loads on first use; raises AmpnetError when it cannot)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmpnetError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
+                          "There is no CPU fallback for the HIP path.")
+    try:
+        l = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise AmpnetError(f"cannot load {LIB_PATH}: {e}") from e
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise AmpnetError(f"two HIP runtimes mapped in one process: {sorted(rts)}")
+    l.ampnet_abi_version.restype = ctypes.c_int
+    l.ampnet_last_error.restype = ctypes.c_char_p
+    v = l.ampnet_abi_version()
+    if v != ABI_VERSION:
+        raise AmpnetError(f"libampnet_hip.so ABI {v} != expected {ABI_VERSION}: rebuild")
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ampnet_last_error()
+        raise AmpnetError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_contiguous():
+        raise AmpnetError("tensor handed to the C ABI must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    """Current torch HIP stream as a void* for the C ABI."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t, name):
+    if not t.is_cuda:
+        raise AmpnetError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")

@@ -1,0 +1,32 @@
+// common.h -- shared helpers of libampnet_hip.so (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/ampnet_hip.h"
+
+namespace ampnet {
+
+constexpr int WAVE = 64;
+
+// thread-local error text returned by ampnet_last_error()
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return AMPNET_OK;
+}
+
+#define AMPNET_REQUIRE(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) return ::ampnet::fail(AMPNET_E_ARG, __VA_ARGS__); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace ampnet
