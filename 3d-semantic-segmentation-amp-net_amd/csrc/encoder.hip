@@ -1,0 +1,311 @@
+// encoder.hip -- C ABI: ampnet_encoder_fwd_f32 = BasePointNet.forward (pointNet/model/pointnetAtt.py:80-112,
+// with TransformationNet.forward :28-47 twice) for ALL windows of a step in one launch sequence.
+//
+// The reference runs the encoder W times per step, once per cluster slot (train_pointnet-attention.py:396-410),
+// so every BatchNorm sees the B windows of one slot.  Here window q = b * W + w and slot(q) = q % n_slots: the
+// statistics stay per slot, the launches cover all Q = B * W windows.  Launch sequence (train mode; eval drops
+// the bn_finalize launches and folds running statistics once):
+//   pw_input(K=3) -> pw_gemm 64->128 -> pw_gemm 128->256 + maxpool -> FC 256->256->128->9 (+I)          input T-Net
+//   pw_input(K=12, per-window T3 folded into conv_1) -> pw_gemm 64->64                                   conv_1, conv_2
+//   pw_gemm 64->64 -> 64->128 -> 128->256 + maxpool -> FC 256->256->128->4096 (+I)                       feature T-Net
+//   pw_gemm 64->64 with per-window weights T64 (the torch.bmm)                                           local features
+//   pw_gemm 64->64 -> 64->128 -> 128->128 -> 128->256 + maxpool                                          conv_3..6, global
+// Every layer stores its PRE-BatchNorm output; BatchNorm + ReLU are applied by the consumer's prologue, the
+// 256-channel pooled layers are never materialised in eval mode (only their per-window max/min).
+#include "encoder.h"
+
+namespace ampnet {
+
+static const int kBnC[BN_ENC_COUNT] = {64, 128, 256, 256, 128, 64, 64, 64, 128, 256, 256, 128, 64, 128, 128, 256};
+
+EncShape enc_shape(int Q, int n_slots, int R, int max_rows, int train)
+{
+    EncShape s;
+    s.Q = Q;
+    s.n_slots = n_slots;
+    s.R = R;
+    s.max_rows = max_rows;
+    s.train = train;
+    s.chunk_rows = 512;
+    s.chunks = cdiv(max_rows, s.chunk_rows);
+    s.fc_rows = Q / n_slots;
+    s.fc_chunk_rows = 128;
+    s.fc_chunks = cdiv(s.fc_rows, s.fc_chunk_rows);
+    return s;
+}
+
+namespace {
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+}  // namespace
+
+void enc_carve(const EncShape &s, void *base, EncWs &ws)
+{
+    Carver c{reinterpret_cast<char *>(base)};
+    const size_t R = (size_t)s.R, Q = (size_t)s.Q;
+    if (s.train) {
+        ws.z_t1 = c.take<float>(R * 64);
+        ws.z_t2 = c.take<float>(R * 128);
+        ws.z_t3 = c.take<float>(R * 256);
+        ws.z_c1 = c.take<float>(R * 64);
+        ws.z_c2 = c.take<float>(R * 64);
+        ws.z_f1 = c.take<float>(R * 64);
+        ws.z_f2 = c.take<float>(R * 128);
+        ws.z_f3 = c.take<float>(R * 256);
+        ws.z_c3 = c.take<float>(R * 64);
+        ws.z_c4 = c.take<float>(R * 128);
+        ws.z_c5 = c.take<float>(R * 128);
+        ws.z_c6 = c.take<float>(R * 256);
+    } else {
+        // eval: four rotating buffers; the 256-channel layers are never stored
+        float *a = c.take<float>(R * 64), *b = c.take<float>(R * 128), *cc = c.take<float>(R * 64), *d = c.take<float>(R * 128);
+        ws.z_t1 = a; ws.z_t2 = b; ws.z_t3 = nullptr;
+        ws.z_c1 = a; ws.z_c2 = cc;
+        ws.z_f1 = a; ws.z_f2 = b; ws.z_f3 = nullptr;
+        ws.z_c3 = a; ws.z_c4 = b; ws.z_c5 = d; ws.z_c6 = nullptr;
+    }
+    ws.pool_t = c.take<float>(Q * 256);
+    ws.z_tf1 = c.take<float>(Q * 256);
+    ws.z_tf2 = c.take<float>(Q * 128);
+    ws.T3 = c.take<float>(Q * 12);
+    ws.pool_f = c.take<float>(Q * 256);
+    ws.z_ff1 = c.take<float>(Q * 256);
+    ws.z_ff2 = c.take<float>(Q * 128);
+    ws.arg_t = c.take<int>(Q * 256);
+    ws.arg_f = c.take<int>(Q * 256);
+    ws.arg_c = c.take<int>(Q * 256);
+    ws.fc_off = c.take<int>((size_t)s.n_slots + 1);
+    const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
+    ws.part_sum = c.take<float>(np);
+    ws.part_sq = c.take<float>(np);
+    ws.part_max = c.take<float>(np);
+    ws.part_min = c.take<float>(np);
+    ws.part_amax = c.take<int>(np);
+    ws.part_amin = c.take<int>(np);
+    for (int i = 0; i < BN_ENC_COUNT; ++i) {
+        const size_t n = (size_t)s.n_slots * kBnC[i];
+        ws.bn[i].C = kBnC[i];
+        ws.bn[i].scale = c.take<float>(n);
+        ws.bn[i].shift = c.take<float>(n);
+        ws.bn[i].mean = c.take<float>(n);
+        ws.bn[i].invstd = c.take<float>(n);
+        ws.bn[i].smean = c.take<float>(n);
+        ws.bn[i].suvar = c.take<float>(n);
+    }
+    ws.bytes = align_up(c.off, 256);
+}
+
+namespace {
+
+struct BnParamRef {
+    const float *gamma, *beta;
+    float *rmean, *rvar;
+};
+
+struct EncRun {
+    hipStream_t st;
+    EncShape s;
+    EncWs ws;
+    const float *const *P;
+    float *const *Bf;
+    const int *win_off;
+    BnParamRef bnp[BN_ENC_COUNT];
+
+    void bind_bn()
+    {
+        auto tn = [&](int base_p, int base_b, int first) {
+            for (int i = 0; i < 5; ++i) {
+                bnp[first + i] = {P[base_p + TP_BN1_W + 2 * i], P[base_p + TP_BN1_B + 2 * i], Bf[base_b + 2 * i], Bf[base_b + 2 * i + 1]};
+            }
+        };
+        tn(EP_IT, EB_IT, BN_T1);
+        tn(EP_FT, EB_FT, BN_F1);
+        const int main_ids[6] = {BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};
+        for (int i = 0; i < 6; ++i)
+            bnp[main_ids[i]] = {P[EP_BN1_W + 2 * i], P[EP_BN1_B + 2 * i], Bf[EB_MAIN + 2 * i], Bf[EB_MAIN + 2 * i + 1]};
+    }
+
+    // point layer on the real windows
+    PwGemm point_layer(const float *A, int cin, const float *W, int cout, int pro_bn, float *Z, bool stats, bool pool) const
+    {
+        PwGemm g;
+        g.A = A; g.lda = cin; g.cin = cin;
+        g.W = W; g.ldw = cin;
+        if (pro_bn >= 0) { g.pro_scale = ws.bn[pro_bn].scale; g.pro_shift = ws.bn[pro_bn].shift; }
+        g.n_slots = s.train ? s.n_slots : 1;
+        g.Z = Z; g.ldz = cout; g.cout = cout;
+        if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        if (pool) { g.part_max = ws.part_max; g.part_min = ws.part_min; g.part_amax = ws.part_amax; g.part_amin = ws.part_amin; }
+        g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        return g;
+    }
+    // FC layer on the pooled rows: n_slots windows of Q / n_slots rows (one window of Q rows in eval mode)
+    PwGemm fc_layer(const float *A, int cin, const float *W, int cout, const float *bias, int pro_bn, float *Z, int ldz, bool stats) const
+    {
+        PwGemm g;
+        g.A = A; g.lda = cin; g.cin = cin;
+        g.W = W; g.ldw = cin; g.bias = bias;
+        if (pro_bn >= 0) { g.pro_scale = ws.bn[pro_bn].scale; g.pro_shift = ws.bn[pro_bn].shift; }
+        g.n_slots = s.train ? s.n_slots : 1;
+        g.Z = Z; g.ldz = ldz; g.cout = cout;
+        if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        g.win_off = ws.fc_off; g.Q = s.n_slots; g.chunk_rows = s.fc_chunk_rows; g.chunks = s.fc_chunks;
+        return g;
+    }
+    int finalize(int bn, bool fc) const
+    {
+        if (!s.train) return AMPNET_OK;
+        BnFinalize f;
+        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq;
+        f.win_off = fc ? ws.fc_off : win_off;
+        f.Q = fc ? s.n_slots : s.Q;
+        f.chunks = fc ? s.fc_chunks : s.chunks;
+        f.n_slots = s.n_slots; f.C = ws.bn[bn].C;
+        f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
+        f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;
+        f.stat_mean = ws.bn[bn].smean; f.stat_uvar = ws.bn[bn].suvar;
+        return bn_finalize(f, st);
+    }
+    int pool(int bn, float *pooled, int *arg, bool slot_major) const
+    {
+        PoolFinalize p;
+        p.part_max = ws.part_max; p.part_min = ws.part_min; p.part_amax = ws.part_amax; p.part_amin = ws.part_amin;
+        p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
+        p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
+        p.out_slot_major = (slot_major && s.train) ? 1 : 0;
+        p.pooled = pooled; p.arg = arg;
+        return pool_finalize(p, st);
+    }
+};
+
+#define TRY(x)                   \
+    do {                         \
+        int rc_ = (x);           \
+        if (rc_ != AMPNET_OK) return rc_; \
+    } while (0)
+
+// one T-Net: conv stack on `A0` ([R, 64] pre-BN with prologue pro0, or the K=3 input layer), FC head -> T [Q, k*k]
+int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0, bool input_k3, float *z1, float *z2, float *z3,
+             float *pooled, int *arg, float *zf1, float *zf2, float *T, int k)
+{
+    const bool tr = e.s.train;
+    if (input_k3) {
+        PwInput in;
+        in.x = x_or_A; in.W = e.P[pbase + TP_CONV1]; in.mode = 0; in.Z = z1;
+        if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
+        in.win_off = e.win_off; in.Q = e.s.Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
+        TRY(pw_input(in, e.st));
+    } else {
+        TRY(pw_gemm(e.point_layer(x_or_A, 64, e.P[pbase + TP_CONV1], 64, pro0, z1, tr, false), e.st));
+    }
+    TRY(e.finalize(bn0 + 0, false));
+    TRY(pw_gemm(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), e.st));
+    TRY(e.finalize(bn0 + 1, false));
+    TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true), e.st));
+    TRY(e.finalize(bn0 + 2, false));
+    TRY(e.pool(bn0 + 2, pooled, arg, true));
+    // FC head on [Q, 256]
+    TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, tr), e.st));
+    TRY(e.finalize(bn0 + 3, true));
+    TRY(pw_gemm(e.fc_layer(zf1, 256, e.P[pbase + TP_FC2], 128, nullptr, bn0 + 3, zf2, 128, tr), e.st));
+    TRY(e.finalize(bn0 + 4, true));
+    TRY(pw_gemm(e.fc_layer(zf2, 128, e.P[pbase + TP_FC3_W], k * k, e.P[pbase + TP_FC3_B], bn0 + 4, T, k * k, false), e.st));
+    TRY(add_identity(T, e.s.Q, k, e.st));
+    return AMPNET_OK;
+}
+
+}  // namespace
+}  // namespace ampnet
+
+using namespace ampnet;
+
+extern "C" size_t ampnet_encoder_workspace_bytes(int Q, int n_slots, int total_rows, int max_rows, int train)
+{
+    if (Q < 1 || n_slots < 1 || total_rows < 1 || max_rows < 1) return 0;
+    EncWs ws;
+    enc_carve(enc_shape(Q, n_slots, total_rows, max_rows, train), nullptr, ws);
+    return ws.bytes;
+}
+
+extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *x,
+                                      const int32_t *win_off, int Q, int n_slots, int total_rows, int max_rows, int train,
+                                      float *local, float *global_feat, float *feat_T, float *in_T, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    AMPNET_REQUIRE(params_host && buffers_host && x && win_off && local && global_feat && feat_T && workspace, "ampnet_encoder_fwd_f32: null pointer");
+    AMPNET_REQUIRE(Q >= 1 && n_slots >= 1 && total_rows >= 1 && max_rows >= 1, "ampnet_encoder_fwd_f32: bad sizes");
+    AMPNET_REQUIRE(!train || Q % n_slots == 0, "ampnet_encoder_fwd_f32: train mode needs Q (%d) %% n_slots (%d) == 0", Q, n_slots);
+    EncRun e;
+    e.st = (hipStream_t)stream;
+    e.s = enc_shape(Q, train ? n_slots : 1, total_rows, max_rows, train);
+    enc_carve(e.s, workspace, e.ws);
+    if (e.ws.bytes > workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_encoder_fwd_f32: workspace %zu B < %zu B", workspace_bytes, e.ws.bytes);
+    e.P = params_host;
+    e.Bf = buffers_host;
+    e.win_off = win_off;
+    e.bind_bn();
+    const bool tr = train != 0;
+
+    TRY(fill_i32_ramp(e.ws.fc_off, e.s.n_slots + 1, e.s.fc_rows, e.st));
+    if (!tr) {
+        BnFoldItem items[BN_ENC_COUNT];
+        for (int i = 0; i < BN_ENC_COUNT; ++i)
+            items[i] = {e.bnp[i].gamma, e.bnp[i].beta, e.bnp[i].rmean, e.bnp[i].rvar, e.ws.bn[i].scale, e.ws.bn[i].shift, e.ws.bn[i].C};
+        TRY(bn_fold(items, BN_ENC_COUNT, 1e-5f, e.st));
+    }
+
+    // input T-Net on xyz
+    TRY(run_tnet(e, EP_IT, BN_T1, x, -1, true, e.ws.z_t1, e.ws.z_t2, e.ws.z_t3, e.ws.pool_t, e.ws.arg_t, e.ws.z_tf1, e.ws.z_tf2, e.ws.T3, 3));
+    // conv_1 on cat(xyz * T3, x), conv_2
+    {
+        PwInput in;
+        in.x = x; in.W = e.P[EP_CONV1]; in.T = e.ws.T3; in.mode = 1;
+        in.perwin_slot_major = tr ? 1 : 0; in.n_slots = e.s.n_slots; in.Z = e.ws.z_c1;
+        if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
+        in.win_off = win_off; in.Q = Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
+        TRY(pw_input(in, e.st));
+        TRY(e.finalize(BN_C1, false));
+    }
+    TRY(pw_gemm(e.point_layer(e.ws.z_c1, 64, e.P[EP_CONV2], 64, BN_C1, e.ws.z_c2, tr, false), e.st));
+    TRY(e.finalize(BN_C2, false));
+    // feature T-Net on relu(bn_2(z_c2))
+    TRY(run_tnet(e, EP_FT, BN_F1, e.ws.z_c2, BN_C2, false, e.ws.z_f1, e.ws.z_f2, e.ws.z_f3, e.ws.pool_f, e.ws.arg_f, e.ws.z_ff1, e.ws.z_ff2, feat_T, 64));
+    // local = relu(bn_2(z_c2)) x T64[window]  (torch.bmm, pointnetAtt.py:96)
+    {
+        PwGemm g = e.point_layer(e.ws.z_c2, 64, feat_T, 64, BN_C2, local, false, false);
+        g.w_win_stride = 64 * 64;
+        g.perwin_slot_major = tr ? 1 : 0;
+        TRY(pw_gemm(g, e.st));
+    }
+    TRY(pw_gemm(e.point_layer(local, 64, e.P[EP_CONV3], 64, -1, e.ws.z_c3, tr, false), e.st));
+    TRY(e.finalize(BN_C3, false));
+    TRY(pw_gemm(e.point_layer(e.ws.z_c3, 64, e.P[EP_CONV4], 128, BN_C3, e.ws.z_c4, tr, false), e.st));
+    TRY(e.finalize(BN_C4, false));
+    TRY(pw_gemm(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), e.st));
+    TRY(e.finalize(BN_C5, false));
+    TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true), e.st));
+    TRY(e.finalize(BN_C6, false));
+    TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, false));
+
+    if (tr) {
+        BnRunItem items[BN_ENC_COUNT];
+        for (int i = 0; i < BN_ENC_COUNT; ++i)
+            items[i] = {e.ws.bn[i].smean, e.ws.bn[i].suvar, e.bnp[i].rmean, e.bnp[i].rvar, e.ws.bn[i].C, e.s.n_slots};
+        TRY(bn_running_update(items, BN_ENC_COUNT, 0.1f, e.st));
+    }
+    if (in_T) {
+        hipError_t err = hipMemcpyAsync(in_T, e.ws.T3, (size_t)Q * 9 * sizeof(float), hipMemcpyDeviceToDevice, e.st);
+        if (err != hipSuccess) return fail(AMPNET_E_LAUNCH, "ampnet_encoder_fwd_f32: copy of the input transform: %s", hipGetErrorString(err));
+    }
+    return AMPNET_OK;
+}

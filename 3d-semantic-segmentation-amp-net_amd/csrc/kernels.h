@@ -1,0 +1,129 @@
+// kernels.h -- internal launch interface between the C-ABI orchestration (encoder.hip, head.hip, ...)
+// and the kernels.  Not part of the public ABI.
+#pragma once
+#include "common.h"
+
+namespace ampnet {
+
+// ----------------------------------------------------------------------------------------------------
+// Per-point linear layer ("shared MLP" = Conv1d k=1) on fp32 MFMA:  Z[row, :] = pro(A[row, :]) * W^T + bias
+//   rows are grouped in windows (win_off[q] .. win_off[q+1]); a workgroup owns one chunk of one window and
+//   one block of <=128 output channels.
+//   pro(a)[k] = relu(a[k] * pro_scale[slot][k] + pro_shift[slot][k]) (the previous layer's BatchNorm + ReLU,
+//   optionally followed by dropout) or the identity when pro_scale == nullptr.
+//   Epilogue options: store Z; per-chunk column sums / sums of squares (BatchNorm statistics of THIS layer);
+//   per-chunk column max / min with their row index (MaxPool1d over the window, before the affine).
+// ----------------------------------------------------------------------------------------------------
+struct PwGemm {
+    const float *A = nullptr;      // [rows, lda]
+    int lda = 0;
+    int cin = 0;                   // 64, 128 or 256
+    const float *W = nullptr;      // shared: [cout, ldw]; per window: [.., cin, cout] k-major (see w_win_stride)
+    int ldw = 0;
+    long w_win_stride = 0;         // != 0: weights of window q start at W + pidx(q) * w_win_stride, layout [cin][cout]
+    const float *bias = nullptr;   // [cout] or per window [.., cout]
+    long bias_win_stride = 0;
+    int perwin_slot_major = 0;     // pidx(q) = (q % n_slots) * (Q / n_slots) + q / n_slots instead of q
+    const float *pro_scale = nullptr;   // [pro_slots, cin]
+    const float *pro_shift = nullptr;
+    int n_slots = 1;               // slot(q) = q % n_slots (batch-statistics groups); 1 in eval mode
+    float drop_p = 0.f;            // dropout on pro(a): keep iff hash(row * cin + k) >= p * 2^32, scaled 1/(1-p)
+    uint32_t drop_seed = 0;
+    float *Z = nullptr;            // [rows, ldz] or nullptr
+    int ldz = 0;
+    int cout = 0;
+    float *part_sum = nullptr;     // [Q * chunks, cout] or nullptr
+    float *part_sq = nullptr;
+    float *part_max = nullptr;     // [Q * chunks, cout] or nullptr
+    float *part_min = nullptr;
+    int *part_amax = nullptr;
+    int *part_amin = nullptr;
+    const int *win_off = nullptr;  // [Q + 1] device
+    int Q = 0;
+    int chunk_rows = 512;
+    int chunks = 1;                // cdiv(max window rows, chunk_rows)
+};
+int pw_gemm(const PwGemm &a, hipStream_t st);
+
+// First layers with a tiny contraction (K = 3 or 12), VALU: Z[row, 0:64] = x[row, cols] * Weff^T
+//   mode 0: Weff = W[64][3] on x[:, 0:3]                                     (T-Net conv_1 on xyz)
+//   mode 1: Weff[c][f] = W[c][3+f] + (f < 3 ? sum_d T[q][f][d] * W[c][d] : 0)  on x[:, 0:9]
+//           = conv_1 of cat(xyz * T, x)                                       (pointnetAtt.py:85-90)
+struct PwInput {
+    const float *x = nullptr;      // [rows, 9]
+    const float *W = nullptr;      // mode 0: [64, 3]; mode 1: [64, 12]
+    const float *T = nullptr;      // mode 1: [.., 3, 3] per window (slot-major index if perwin_slot_major)
+    int mode = 0;
+    int perwin_slot_major = 0;
+    int n_slots = 1;
+    float *Z = nullptr;            // [rows, 64]
+    float *part_sum = nullptr, *part_sq = nullptr;    // [Q * chunks, 64] or nullptr
+    const int *win_off = nullptr;
+    int Q = 0, chunk_rows = 512, chunks = 1;
+};
+int pw_input(const PwInput &a, hipStream_t st);
+
+// BatchNorm statistics -> affine.  One block per (slot, 64 channels).
+struct BnFinalize {
+    const float *part_sum = nullptr, *part_sq = nullptr;   // [Q * chunks, C]
+    const int *win_off = nullptr;
+    int Q = 0, chunks = 1, n_slots = 1, C = 0;
+    const float *gamma = nullptr, *beta = nullptr;
+    float eps = 1e-5f;
+    float *scale = nullptr, *shift = nullptr;   // [n_slots, C]   y = z * scale + shift
+    float *mean = nullptr, *invstd = nullptr;   // [n_slots, C]   (saved for backward)
+    float *stat_mean = nullptr, *stat_uvar = nullptr;   // [n_slots, C] batch mean / unbiased var for the running update
+};
+int bn_finalize(const BnFinalize &a, hipStream_t st);
+
+// eval mode: scale/shift from running statistics for a list of layers, one launch
+struct BnFoldItem {
+    const float *gamma, *beta, *rmean, *rvar;
+    float *scale, *shift;
+    int C;
+};
+int bn_fold(const BnFoldItem *items_host, int n_items, float eps, hipStream_t st);
+
+// train mode: running statistics update for a list of layers, sequential over slots like W encoder calls
+struct BnRunItem {
+    const float *stat_mean, *stat_uvar;   // [n_slots, C]
+    float *rmean, *rvar;
+    int C, n_slots;
+};
+int bn_running_update(const BnRunItem *items_host, int n_items, float momentum, hipStream_t st);
+
+// MaxPool1d over each window after BatchNorm + ReLU:
+//   pooled[orow(q), c] = relu(scale * (scale >= 0 ? max : min) + shift), arg[q, c] = row index of that extreme
+struct PoolFinalize {
+    const float *part_max = nullptr, *part_min = nullptr;
+    const int *part_amax = nullptr, *part_amin = nullptr;
+    const float *scale = nullptr, *shift = nullptr;   // [n_slots, C]
+    int Q = 0, chunks = 1, n_slots = 1, C = 0;
+    int out_slot_major = 0;       // orow(q) = (q % n_slots) * (Q / n_slots) + q / n_slots, else q
+    float *pooled = nullptr;      // [Q, C]
+    int *arg = nullptr;           // [Q, C] or nullptr
+};
+int pool_finalize(const PoolFinalize &a, hipStream_t st);
+
+// small elementwise helpers
+int add_identity(float *T, int n_mats, int k, hipStream_t st);                    // T[m] += I_k
+int fill_i32_ramp(int *dst, int n, int step, hipStream_t st);                     // dst[i] = i * step
+
+// dropout hash shared by kernels (lowbias32), restated in oracle/ampnet_oracle.py:keep_mask
+__host__ __device__ inline uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t drop_base(uint32_t seed, uint32_t stream) { return mix32(seed + stream * 0x9E3779B9U); }
+__host__ __device__ inline uint32_t drop_threshold(float p)
+{
+    double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFU : (uint32_t)t;
+}
+
+}  // namespace ampnet

@@ -1,0 +1,269 @@
+// pw_misc.hip -- the small kernels around pw_gemm: the K<=12 input layers (VALU), BatchNorm statistic
+// finalisation / folding / running update, and the MaxPool finalisation.
+//
+// Reference ops (pointNet/model/pointnetAtt.py): input T-Net conv_1 (:31, K = 3), encoder conv_1 on
+// cat(xyz * T, x) (:85-90, K = 12), every nn.BatchNorm1d (:17-22, :73-78, :173-174; eps 1e-5, momentum 0.1,
+// unbiased running variance) and nn.MaxPool1d(num_points) (:35, :104).
+#include "kernels.h"
+
+namespace ampnet {
+
+// ----------------------------------------------------------------------------------------------------
+// pw_input: 64 output channels, lane = channel, a wave walks rows.  HBM-bound (36 B in, 256 B out per
+// point), so the layout that matters is the coalesced 256-byte row store; x rows are staged through LDS.
+// ----------------------------------------------------------------------------------------------------
+constexpr int IN_ROWS = 256;   // rows staged per pass
+
+__global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
+{
+    __shared__ float sx[IN_ROWS * 9];
+    __shared__ float red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.y, chunk = blockIdx.x;
+    const int row_begin = a.win_off[q] + chunk * a.chunk_rows;
+    const int row_end = min(a.win_off[q + 1], row_begin + a.chunk_rows);
+
+    // effective weights of this lane's output channel
+    float w[9];
+    if (a.mode == 0) {
+#pragma unroll
+        for (int f = 0; f < 9; ++f) w[f] = f < 3 ? a.W[lane * 3 + f] : 0.f;
+    } else {
+        const int pidx = a.perwin_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+        const float *T = a.T + (size_t)pidx * 9;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            float v = a.W[lane * 12 + 3 + f];
+            if (f < 3) v += T[f * 3 + 0] * a.W[lane * 12 + 0] + T[f * 3 + 1] * a.W[lane * 12 + 1] + T[f * 3 + 2] * a.W[lane * 12 + 2];
+            w[f] = v;
+        }
+    }
+    const int nf = a.mode == 0 ? 3 : 9;
+    float s = 0.f, sq = 0.f;
+    for (int base = row_begin; base < row_end; base += IN_ROWS) {
+        const int n = min(IN_ROWS, row_end - base);
+        __syncthreads();
+        for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
+        __syncthreads();
+        for (int i = wave; i < n; i += 4) {
+            float z = 0.f;
+            if (nf == 3) {
+                z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
+            } else {
+#pragma unroll
+                for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+            }
+            a.Z[(size_t)(base + i) * 64 + lane] = z;
+            s += z;
+            sq = fmaf(z, z, sq);
+        }
+    }
+    if (a.part_sum) {
+        red[wave][lane][0] = s;
+        red[wave][lane][1] = sq;
+        __syncthreads();
+        if (wave == 0) {
+            const float ts = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
+            const float tq = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+            const size_t o = (size_t)(q * a.chunks + chunk) * 64 + lane;
+            a.part_sum[o] = ts;
+            a.part_sq[o] = tq;
+        }
+    }
+}
+
+int pw_input(const PwInput &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.x && a.W && a.Z && a.win_off, "pw_input: null pointer");
+    AMPNET_REQUIRE(a.mode == 0 || a.T, "pw_input: mode 1 needs T");
+    AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_input: partials");
+    hipLaunchKernelGGL(pw_input_kernel, dim3(a.chunks, a.Q), dim3(256), 0, st, a);
+    return check_launch("pw_input_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// bn_finalize: block = (slot, 64 channels) x 4 row groups; sums the per-chunk partials of the windows of the
+// slot in a fixed order in double, so results are bitwise reproducible run to run.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
+{
+    __shared__ double rs[4][64], rq[4][64];
+    __shared__ int rows_s;
+    const int slot = blockIdx.x;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;     // windows q = slot, slot + n_slots, ...
+    double s = 0.0, sq = 0.0;
+    if (c < a.C) {
+        const int total = per_slot * a.chunks;
+        for (int e = g; e < total; e += 4) {
+            const int q = slot + (e / a.chunks) * a.n_slots;
+            const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
+            s += (double)a.part_sum[o];
+            sq += (double)a.part_sq[o];
+        }
+    }
+    rs[g][cl] = s;
+    rq[g][cl] = sq;
+    if (threadIdx.x == 0) {
+        int rows = 0;
+        for (int i = 0; i < per_slot; ++i) {
+            const int q = slot + i * a.n_slots;
+            rows += a.win_off[q + 1] - a.win_off[q];
+        }
+        rows_s = rows;
+    }
+    __syncthreads();
+    if (g == 0 && c < a.C) {
+        const double n = (double)rows_s;
+        const double ts = (rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl]);
+        const double tq = (rq[0][cl] + rq[1][cl]) + (rq[2][cl] + rq[3][cl]);
+        const double mean = ts / n;
+        double var = tq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = a.gamma[c] * invstd;
+        const size_t o = (size_t)slot * a.C + c;
+        a.scale[o] = sc;
+        a.shift[o] = a.beta[c] - (float)mean * sc;
+        if (a.mean) a.mean[o] = (float)mean;
+        if (a.invstd) a.invstd[o] = invstd;
+        if (a.stat_mean) {
+            a.stat_mean[o] = (float)mean;
+            a.stat_uvar[o] = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        }
+    }
+}
+
+int bn_finalize(const BnFinalize &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.part_sum && a.part_sq && a.win_off && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(256), 0, st, a);
+    return check_launch("bn_finalize_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// bn_fold / bn_running_update: a list of layers per launch (items in kernel arguments, <= 24 layers)
+// ----------------------------------------------------------------------------------------------------
+constexpr int MAX_ITEMS = 24;
+struct FoldArgs {
+    BnFoldItem it[MAX_ITEMS];
+    int n;
+    float eps;
+};
+struct RunArgs {
+    BnRunItem it[MAX_ITEMS];
+    int n;
+    float momentum;
+};
+
+__global__ void bn_fold_kernel(FoldArgs a)
+{
+    const BnFoldItem it = a.it[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += blockDim.x) {
+        const float invstd = 1.0f / sqrtf(it.rvar[c] + a.eps);
+        const float sc = it.gamma[c] * invstd;
+        it.scale[c] = sc;
+        it.shift[c] = it.beta[c] - it.rmean[c] * sc;
+    }
+}
+
+__global__ void bn_running_kernel(RunArgs a)
+{
+    const BnRunItem it = a.it[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += blockDim.x) {
+        float m = it.rmean[c], v = it.rvar[c];
+        for (int s = 0; s < it.n_slots; ++s) {      // slot order = the order of the reference's W encoder calls
+            m = (1.0f - a.momentum) * m + a.momentum * it.stat_mean[(size_t)s * it.C + c];
+            v = (1.0f - a.momentum) * v + a.momentum * it.stat_uvar[(size_t)s * it.C + c];
+        }
+        it.rmean[c] = m;
+        it.rvar[c] = v;
+    }
+}
+
+int bn_fold(const BnFoldItem *items, int n, float eps, hipStream_t st)
+{
+    AMPNET_REQUIRE(n >= 1 && n <= MAX_ITEMS, "bn_fold: %d items", n);
+    FoldArgs a;
+    for (int i = 0; i < n; ++i) a.it[i] = items[i];
+    a.n = n;
+    a.eps = eps;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(n), dim3(256), 0, st, a);
+    return check_launch("bn_fold_kernel");
+}
+
+int bn_running_update(const BnRunItem *items, int n, float momentum, hipStream_t st)
+{
+    AMPNET_REQUIRE(n >= 1 && n <= MAX_ITEMS, "bn_running_update: %d items", n);
+    RunArgs a;
+    for (int i = 0; i < n; ++i) a.it[i] = items[i];
+    a.n = n;
+    a.momentum = momentum;
+    hipLaunchKernelGGL(bn_running_kernel, dim3(n), dim3(256), 0, st, a);
+    return check_launch("bn_running_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pool_finalize: relu(scale * extreme + shift) where extreme = max for scale >= 0, min otherwise
+// (BatchNorm then ReLU are monotone per channel, so MaxPool commutes with them up to the sign of scale).
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
+{
+    const int q = blockIdx.x;
+    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+    const int orow = a.out_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        const float sc = a.scale[(size_t)slot * a.C + c], sh = a.shift[(size_t)slot * a.C + c];
+        float best = 0.f;
+        int arg = -1;
+        const bool use_max = sc >= 0.f;
+        for (int ch = 0; ch < a.chunks; ++ch) {
+            const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
+            const float v = use_max ? a.part_max[o] : a.part_min[o];
+            const int i = use_max ? a.part_amax[o] : a.part_amin[o];
+            if (i < 0) continue;
+            if (arg < 0 || (use_max ? v > best : v < best)) {     // chunks ascend in row order: first extreme wins
+                best = v;
+                arg = i;
+            }
+        }
+        a.pooled[(size_t)orow * a.C + c] = fmaxf(fmaf(best, sc, sh), 0.f);
+        if (a.arg) a.arg[(size_t)q * a.C + c] = arg;
+    }
+}
+
+int pool_finalize(const PoolFinalize &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.part_max && a.part_min && a.part_amax && a.part_amin && a.scale && a.shift && a.pooled, "pool_finalize: null pointer");
+    AMPNET_REQUIRE(!a.out_slot_major || a.Q % a.n_slots == 0, "pool_finalize: Q %% n_slots != 0");
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3(a.Q), dim3(256), 0, st, a);
+    return check_launch("pool_finalize_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+__global__ void add_identity_kernel(float *T, int n_mats, int k)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mats * k) T[(size_t)(i / k) * k * k + (i % k) * (k + 1)] += 1.0f;
+}
+
+int add_identity(float *T, int n_mats, int k, hipStream_t st)
+{
+    hipLaunchKernelGGL(add_identity_kernel, dim3(cdiv(n_mats * k, 256)), dim3(256), 0, st, T, n_mats, k);
+    return check_launch("add_identity_kernel");
+}
+
+__global__ void ramp_kernel(int *dst, int n, int step)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i * step;
+}
+
+int fill_i32_ramp(int *dst, int n, int step, hipStream_t st)
+{
+    hipLaunchKernelGGL(ramp_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dst, n, step);
+    return check_launch("ramp_kernel");
+}
+
+}  // namespace ampnet

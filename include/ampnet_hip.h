@@ -56,6 +56,47 @@ int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t
 int ampnet_gather_rows_f32(const float *src, const int32_t *idx, int n_clouds, int n, int ld, int s,
                            float *out, void *stream);
 
+/* ---- parameter tables -----------------------------------------------------------------------------
+ * Model parameters cross the ABI as HOST arrays of DEVICE pointers, one entry per state_dict tensor of the
+ * reference modules, in the fixed order below (the order of `params.ENC_PARAMS` / `ENC_BUFFERS` /
+ * `HEAD_PARAMS` / `HEAD_BUFFERS` in the Python package; ampnet_*_name(i) returns the state_dict key):
+ *   encoder params  (52): input_transform.{conv_1,conv_2,conv_3}.weight, bn_1..5.{weight,bias},
+ *                         fc_1.weight, fc_2.weight, fc_3.{weight,bias}; feature_transform.<same 17>;
+ *                         conv_1..6.weight; bn_1..6.{weight,bias}          (pointnetAtt.py:14-26, 66-78)
+ *   encoder buffers (32): (running_mean, running_var) of input_transform.bn_1..5, feature_transform.bn_1..5,
+ *                         bn_1..6
+ *   head params     (18): fc1.{weight,bias}, fc2.{weight,bias}, attention.in_proj_{weight,bias},
+ *                         attention.out_proj.{weight,bias}, conv_2.{weight,bias}, conv_3.{weight,bias},
+ *                         conv_4.{weight,bias}, bn_2.{weight,bias}, bn_3.{weight,bias}   (pointnetAtt.py:160-174)
+ *   head buffers     (4): (running_mean, running_var) of bn_2, bn_3
+ * Only the AMP-Net configuration is built: point_dimension 3, 9 features, global 256, local 64,
+ * 8 heads, <= 8 classes (train_pointnet-attention.py:110-118).                                      */
+int ampnet_table_count(int table);                 /* table: 0 enc params, 1 enc buffers, 2 head params, 3 head buffers */
+const char *ampnet_table_name(int table, int i);
+long ampnet_table_numel(int table, int i);
+
+/* ---- a2/a3: encoder forward ---------------------------------------------------------------------
+ * replaces BasePointNet.forward (pointNet/model/pointnetAtt.py:80-112; TransformationNet.forward :28-47) for the
+ * W encoder calls of one step (train_pointnet-attention.py:396-410) at once.
+ *   x          [total_rows, 9]      the windows back to back; window q = rows win_off[q] .. win_off[q+1]
+ *   win_off    [Q + 1] int32 (device); max_rows = the largest window
+ *   n_slots    windows q with equal q % n_slots share BatchNorm batch statistics (train); Q = B * n_slots with
+ *              q = b * n_slots + w.  Ignored in eval mode (running statistics).
+ *   local      [total_rows, 64]     local_point_features (:97)
+ *   global_feat[Q, 256]             max-pooled global feature (:104-106), row q
+ *   feat_T     [Q, 64, 64]          feature_transform (:94); in_T [Q, 3, 3] input_transform (:84), may be NULL.
+ *              Row order of feat_T / in_T: eval: q.  train: slot-major, row (q % n_slots) * (Q / n_slots) + q / n_slots,
+ *              so the LAST slot's B matrices (what the reference's reg loss uses, train_pointnet-attention.py:463)
+ *              are the last B rows.
+ *   train != 0: batch statistics, running statistics updated in place (momentum 0.1, one update per slot in
+ *              slot order, like W encoder calls); the workspace then holds what ampnet_encoder_bwd_f32 needs.
+ * Eval logits built on these outputs match the reference CPU forward within 1e-3 (tests/test_forward_gpu.py). */
+size_t ampnet_encoder_workspace_bytes(int Q, int n_slots, int total_rows, int max_rows, int train);
+int ampnet_encoder_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *x,
+                           const int32_t *win_off, int Q, int n_slots, int total_rows, int max_rows, int train,
+                           float *local, float *global_feat, float *feat_T, float *in_T, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
