@@ -1,0 +1,190 @@
+// head.hip -- C ABI: ampnet_head_fwd_f32 = SegmentationWithAttention.forward (pointNet/model/pointnetAtt.py:176-209)
+// plus the loss/argmax of train_pointnet-attention.py:445-450.
+//
+// What the reference materialises and this path does not: the per-cluster repeat + cat of the 256-d attention
+// token over every point (:192-201, a [B, 320, P] tensor = 755 MB at B = 32).  conv_2 over cat(local, token) is
+//     W[:, :64] . local[point]  +  (W[:, 64:] . token[window] + bias)
+// so the token part is a per-WINDOW bias vector [Q, 128] computed once by a small GEMM and added in the
+// epilogue of the 64 -> 128 per-point GEMM.  Launch sequence:
+//   posenc_tokens -> pw_gemm 256->768 (in_proj) -> attention_core -> pw_gemm 256->256 (out_proj)
+//   -> pw_gemm 256->128 (token half of conv_2) -> pw_gemm 64->128 (+per-window bias, bn_2 stats)
+//   -> pw_gemm 128->64 (bn_2+ReLU+dropout prologue, bn_3 stats) -> head_out (bn_3+ReLU+dropout, conv_4, CE, argmax)
+#include "head.h"
+
+namespace ampnet {
+
+HeadShape head_shape(int B, int W, int R, int max_rows, int n_classes, int train)
+{
+    HeadShape s;
+    s.B = B;
+    s.W = W;
+    s.Q = B * W;
+    s.R = R;
+    s.max_rows = max_rows;
+    s.train = train;
+    s.n_classes = n_classes;
+    s.chunk_rows = 512;
+    s.chunks = cdiv(max_rows, s.chunk_rows);
+    s.tok_chunk_rows = 128;
+    s.tok_chunks = cdiv(s.Q, s.tok_chunk_rows);
+    return s;
+}
+
+namespace {
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+void carve_bn(Carver &c, BnSlot1 &b, int C)
+{
+    b.C = C;
+    b.scale = c.take<float>(C);
+    b.shift = c.take<float>(C);
+    b.mean = c.take<float>(C);
+    b.invstd = c.take<float>(C);
+    b.smean = c.take<float>(C);
+    b.suvar = c.take<float>(C);
+}
+}  // namespace
+
+void head_carve(const HeadShape &s, void *base, HeadWs &ws)
+{
+    Carver c{reinterpret_cast<char *>(base)};
+    const size_t Q = (size_t)s.Q, R = (size_t)s.R;
+    ws.tok = c.take<float>(Q * 256);
+    ws.qkv = c.take<float>(Q * 768);
+    ws.probs = c.take<float>((size_t)s.B * HEAD_HEADS * s.W * s.W);
+    ws.ctx = c.take<float>(Q * 256);
+    ws.g2 = c.take<float>(Q * 256);
+    ws.gbias = c.take<float>(Q * 128);
+    ws.z2 = c.take<float>(R * 128);
+    ws.z3 = c.take<float>(R * 64);
+    ws.tok_off = c.take<int>(2);
+    const size_t np = (Q * (size_t)s.chunks > (size_t)s.tok_chunks ? Q * (size_t)s.chunks : (size_t)s.tok_chunks) * 128;
+    ws.part_sum = c.take<float>(np);
+    ws.part_sq = c.take<float>(np);
+    ws.loss_part = c.take<float>((size_t)cdiv(s.R, 128) * 2);
+    carve_bn(c, ws.bn2, 128);
+    carve_bn(c, ws.bn3, 64);
+    ws.bytes = align_up(c.off, 256);
+}
+
+}  // namespace ampnet
+
+using namespace ampnet;
+
+#define TRY(x)                            \
+    do {                                  \
+        int rc_ = (x);                    \
+        if (rc_ != AMPNET_OK) return rc_; \
+    } while (0)
+
+extern "C" size_t ampnet_head_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes, int train)
+{
+    if (B < 1 || W < 1 || total_rows < 1 || max_rows < 1) return 0;
+    HeadWs ws;
+    head_carve(head_shape(B, W, total_rows, max_rows, n_classes, train), nullptr, ws);
+    return ws.bytes;
+}
+
+extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl,
+                                   const float *lo, const float *centroids, const int32_t *win_off,
+                                   const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
+                                   int train, float drop_p, uint32_t seed, float *logits, const long long *targets,
+                                   const float *class_w, long long *preds, float *loss_out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    AMPNET_REQUIRE(params_host && buffers_host && gl && lo && centroids && win_off && logits && workspace, "ampnet_head_fwd_f32: null pointer");
+    AMPNET_REQUIRE(B >= 1 && W >= 1 && W <= HEAD_MAX_W, "ampnet_head_fwd_f32: B=%d W=%d (W <= %d)", B, W, HEAD_MAX_W);
+    AMPNET_REQUIRE(total_rows >= 1 && total_rows % B == 0, "ampnet_head_fwd_f32: total_rows %d not a multiple of B %d", total_rows, B);
+    AMPNET_REQUIRE(n_classes >= 1 && n_classes <= HEAD_MAX_CLASSES, "ampnet_head_fwd_f32: n_classes=%d", n_classes);
+    AMPNET_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ampnet_head_fwd_f32: dropout p=%f", drop_p);
+    AMPNET_REQUIRE(!loss_out || targets, "ampnet_head_fwd_f32: loss_out needs targets");
+    hipStream_t st = (hipStream_t)stream;
+    const HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, train);
+    HeadWs ws;
+    head_carve(s, workspace, ws);
+    if (ws.bytes > workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_head_fwd_f32: workspace %zu B < %zu B", workspace_bytes, ws.bytes);
+    const float *const *P = params_host;
+    const bool tr = train != 0;
+    const float dp = tr ? drop_p : 0.f;
+    const int Q = s.Q;
+
+    TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
+    TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
+    auto tok_gemm = [&](const float *A, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
+        PwGemm g;
+        g.A = A; g.lda = 256; g.cin = 256;
+        g.W = Wm; g.ldw = ldw; g.bias = bias;
+        g.Z = Z; g.ldz = cout; g.cout = cout;
+        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks;
+        return pw_gemm(g, st);
+    };
+    TRY(tok_gemm(ws.tok, P[HP_INPROJ_W], 256, P[HP_INPROJ_B], 768, ws.qkv));
+    TRY(attention_core(ws.qkv, key_pad_mask, ws.probs, ws.ctx, B, W, dp, drop_base(seed, 0), st));
+    TRY(tok_gemm(ws.ctx, P[HP_OUTPROJ_W], 256, P[HP_OUTPROJ_B], 256, ws.g2));
+    TRY(tok_gemm(ws.g2, P[HP_CONV2_W] + 64, 320, P[HP_CONV2_B], 128, ws.gbias));   // token half of conv_2 + its bias
+
+    if (!tr) {
+        BnFoldItem items[2] = {{P[HP_BN2_W], P[HP_BN2_B], buffers_host[HB_BN2_MEAN], buffers_host[HB_BN2_VAR], ws.bn2.scale, ws.bn2.shift, 128},
+                               {P[HP_BN3_W], P[HP_BN3_B], buffers_host[HB_BN3_MEAN], buffers_host[HB_BN3_VAR], ws.bn3.scale, ws.bn3.shift, 64}};
+        TRY(bn_fold(items, 2, 1e-5f, st));
+    }
+    auto finalize = [&](BnSlot1 &b, int wi, int bi) {
+        BnFinalize f;
+        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.chunk_rows = s.chunk_rows;
+        f.win_off = win_off; f.Q = Q; f.chunks = s.chunks; f.n_slots = 1; f.C = b.C;
+        f.gamma = P[wi]; f.beta = P[bi];
+        f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
+        return bn_finalize(f, st);
+    };
+    {   // conv_2: local half + per-window token bias
+        PwGemm g;
+        g.A = lo; g.lda = 64; g.cin = 64;
+        g.W = P[HP_CONV2_W]; g.ldw = 320;
+        g.bias = ws.gbias; g.bias_win_stride = 128;
+        g.Z = ws.z2; g.ldz = 128; g.cout = 128;
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        TRY(pw_gemm(g, st));
+        if (tr) TRY(finalize(ws.bn2, HP_BN2_W, HP_BN2_B));
+    }
+    {   // conv_3 on dropout(relu(bn_2(z2)))
+        PwGemm g;
+        g.A = ws.z2; g.lda = 128; g.cin = 128;
+        g.W = P[HP_CONV3_W]; g.ldw = 128; g.bias = P[HP_CONV3_B];
+        g.pro_scale = ws.bn2.scale; g.pro_shift = ws.bn2.shift;
+        g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
+        g.Z = ws.z3; g.ldz = 64; g.cout = 64;
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        TRY(pw_gemm(g, st));
+        if (tr) TRY(finalize(ws.bn3, HP_BN3_W, HP_BN3_B));
+    }
+    {
+        HeadOut o;
+        o.z3 = ws.z3; o.scale = ws.bn3.scale; o.shift = ws.bn3.shift;
+        o.W = P[HP_CONV4_W]; o.bias = P[HP_CONV4_B];
+        o.drop_p = dp; o.drop_seed = drop_base(seed, 2);
+        o.R = total_rows; o.P = total_rows / B; o.C = n_classes;
+        o.logits = logits; o.targets = targets; o.class_w = class_w; o.preds = preds;
+        o.loss_part = loss_out ? ws.loss_part : nullptr;
+        int blocks = 0;
+        TRY(head_out(o, &blocks, st));
+        if (loss_out) TRY(loss_finalize(ws.loss_part, blocks, loss_out, st));
+    }
+    if (tr) {
+        BnRunItem items[2] = {{ws.bn2.smean, ws.bn2.suvar, buffers_host[HB_BN2_MEAN], buffers_host[HB_BN2_VAR], 128, 1},
+                              {ws.bn3.smean, ws.bn3.suvar, buffers_host[HB_BN3_MEAN], buffers_host[HB_BN3_VAR], 64, 1}};
+        TRY(bn_running_update(items, 2, 0.1f, st));
+    }
+    return AMPNET_OK;
+}

@@ -32,8 +32,8 @@ struct PwGemm {
     float *Z = nullptr;            // [rows, ldz] or nullptr
     int ldz = 0;
     int cout = 0;
-    float *part_sum = nullptr;     // [Q * chunks, cout] or nullptr
-    float *part_sq = nullptr;
+    float *part_sum = nullptr;     // [Q * chunks, cout] or nullptr: per-chunk MEAN of each output column
+    float *part_sq = nullptr;      //                               per-chunk sum of squared deviations from it
     float *part_max = nullptr;     // [Q * chunks, cout] or nullptr
     float *part_min = nullptr;
     int *part_amax = nullptr;
@@ -57,7 +57,7 @@ struct PwInput {
     int perwin_slot_major = 0;
     int n_slots = 1;
     float *Z = nullptr;            // [rows, 64]
-    float *part_sum = nullptr, *part_sq = nullptr;    // [Q * chunks, 64] or nullptr
+    float *part_sum = nullptr, *part_sq = nullptr;    // [Q * chunks, 64] or nullptr (chunk mean, chunk M2)
     const int *win_off = nullptr;
     int Q = 0, chunk_rows = 512, chunks = 1;
 };
@@ -65,7 +65,8 @@ int pw_input(const PwInput &a, hipStream_t st);
 
 // BatchNorm statistics -> affine.  One block per (slot, 64 channels).
 struct BnFinalize {
-    const float *part_sum = nullptr, *part_sq = nullptr;   // [Q * chunks, C]
+    const float *part_sum = nullptr, *part_sq = nullptr;   // [Q * chunks, C] chunk mean, chunk M2
+    int chunk_rows = 512;
     const int *win_off = nullptr;
     int Q = 0, chunks = 1, n_slots = 1, C = 0;
     const float *gamma = nullptr, *beta = nullptr;

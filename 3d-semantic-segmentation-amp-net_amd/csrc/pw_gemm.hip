@@ -92,10 +92,15 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const bool do_stats = a.part_sum != nullptr;
     const bool do_pool = a.part_max != nullptr;
 
-    float s_sum[NT], s_sq[NT], s_max[NT], s_min[NT];
+    // BatchNorm statistics are accumulated as sums of (v - z0) and (v - z0)^2 with z0 = the wave's first
+    // row: E[z^2] - mean^2 in fp32 loses everything when a channel's spread is small against its mean
+    // (the T-Net FC layers normalise over only B rows of near-identical pooled features).
+    float s_sum[NT], s_sq[NT], s_max[NT], s_min[NT], s_z0[NT];
     int s_amax[NT], s_amin[NT];
+    int s_cnt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        s_z0[t] = 0.f;
         s_sum[t] = 0.f;
         s_sq[t] = 0.f;
         s_max[t] = -__builtin_inff();
@@ -181,6 +186,13 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
 
         // ---- epilogue: lane = output channel, registers = 16 rows ----
+        if (do_stats) {
+            if (tile == wave) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) s_z0[t] = __shfl(acc[t][0] + bias_v[t], r);   // row0 + 0 lives in lane r, register 0
+            }
+            s_cnt += valid;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = cb0 + 32 * t + r;
@@ -192,8 +204,9 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 const bool ok = rr < valid;
                 if (a.Z && ok && cok) a.Z[(size_t)(row0 + rr) * a.ldz + col] = v;
                 if (do_stats && ok) {
-                    s_sum[t] += v;
-                    s_sq[t] = fmaf(v, v, s_sq[t]);
+                    const float d = v - s_z0[t];
+                    s_sum[t] += d;
+                    s_sq[t] = fmaf(d, d, s_sq[t]);
                 }
                 if (do_pool && ok) {
                     if (v > s_max[t]) {
@@ -213,8 +226,9 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 
     // ---- combine the two half-waves, then the waves (LDS scratch reuses the weight tile) ----
     __syncthreads();
-    float *red_f = smem;                                        // [PW_NW][CB][4]: sum, sq, max, min
-    int *red_i = reinterpret_cast<int *>(smem + PW_NW * CB * 4);   // [PW_NW][CB][2]: amax, amin
+    float *red_f = smem;                                           // [PW_NW][CB][5]: S1, S2, max, min, z0
+    int *red_i = reinterpret_cast<int *>(smem + PW_NW * CB * 5);   // [PW_NW][CB][2]: amax, amin
+    int *red_n = red_i + PW_NW * CB * 2;                           // [PW_NW] rows seen by the wave
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float o_sum = __shfl_xor(s_sum[t], 32), o_sq = __shfl_xor(s_sq[t], 32);
@@ -232,25 +246,36 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
         if (h == 0) {
             const int c = 32 * t + r;
-            red_f[(wave * CB + c) * 4 + 0] = s_sum[t] + o_sum;
-            red_f[(wave * CB + c) * 4 + 1] = s_sq[t] + o_sq;
-            red_f[(wave * CB + c) * 4 + 2] = f_max;
-            red_f[(wave * CB + c) * 4 + 3] = f_min;
+            red_f[(wave * CB + c) * 5 + 0] = s_sum[t] + o_sum;
+            red_f[(wave * CB + c) * 5 + 1] = s_sq[t] + o_sq;
+            red_f[(wave * CB + c) * 5 + 2] = f_max;
+            red_f[(wave * CB + c) * 5 + 3] = f_min;
+            red_f[(wave * CB + c) * 5 + 4] = s_z0[t];
             red_i[(wave * CB + c) * 2 + 0] = f_amax;
             red_i[(wave * CB + c) * 2 + 1] = f_amin;
         }
     }
+    if (lane == 0) red_n[wave] = s_cnt;
     __syncthreads();
     for (int c = tid; c < CB; c += PW_NW * 64) {
         const int col = cb0 + c;
         if (col >= a.cout) continue;
-        float sum = 0.f, sq = 0.f, mx = -__builtin_inff(), mn = __builtin_inff();
+        double n = 0.0, mean = 0.0, m2 = 0.0;                      // Chan's pairwise merge, fixed wave order
+        float mx = -__builtin_inff(), mn = __builtin_inff();
         int amx = -1, amn = -1;
 #pragma unroll
         for (int w = 0; w < PW_NW; ++w) {
-            sum += red_f[(w * CB + c) * 4 + 0];
-            sq += red_f[(w * CB + c) * 4 + 1];
-            const float vmx = red_f[(w * CB + c) * 4 + 2], vmn = red_f[(w * CB + c) * 4 + 3];
+            const double nw = (double)red_n[w];
+            if (do_stats && nw > 0.0) {
+                const double s1 = red_f[(w * CB + c) * 5 + 0], s2 = red_f[(w * CB + c) * 5 + 1];
+                const double mw = (double)red_f[(w * CB + c) * 5 + 4] + s1 / nw;
+                const double m2w = s2 - s1 * s1 / nw;
+                const double nn = n + nw, delta = mw - mean;
+                mean += delta * nw / nn;
+                m2 += m2w + delta * delta * n * nw / nn;
+                n = nn;
+            }
+            const float vmx = red_f[(w * CB + c) * 5 + 2], vmn = red_f[(w * CB + c) * 5 + 3];
             const int imx = red_i[(w * CB + c) * 2 + 0], imn = red_i[(w * CB + c) * 2 + 1];
             if (vmx > mx || (vmx == mx && (unsigned)imx < (unsigned)amx)) {
                 mx = vmx;
@@ -263,8 +288,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
         if (do_stats) {
-            a.part_sum[o] = sum;
-            a.part_sq[o] = sq;
+            a.part_sum[o] = (float)mean;            // chunk mean
+            a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
         if (do_pool) {
             a.part_max[o] = mx;
@@ -280,7 +305,7 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
-    constexpr size_t lds_red = (size_t)PW_NW * CB * 6 * sizeof(float);
+    constexpr size_t lds_red = (size_t)(PW_NW * CB * 7 + PW_NW) * sizeof(float);
     constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
     static bool attr_set = false;
     auto kern = pw_gemm_kernel<CIN, NT>;

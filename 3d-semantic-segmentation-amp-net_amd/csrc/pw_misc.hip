@@ -17,7 +17,8 @@ constexpr int IN_ROWS = 256;   // rows staged per pass
 __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
 {
     __shared__ float sx[IN_ROWS * 9];
-    __shared__ float red[4][64][2];
+    __shared__ float red[4][64][3];
+    __shared__ int red_n[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.y, chunk = blockIdx.x;
     const int row_begin = a.win_off[q] + chunk * a.chunk_rows;
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
         }
     }
     const int nf = a.mode == 0 ? 3 : 9;
-    float s = 0.f, sq = 0.f;
+    float s = 0.f, sq = 0.f, z0 = 0.f;     // sums of (z - z0), (z - z0)^2 with z0 = the wave's first row (see pw_gemm.hip)
+    int cnt = 0;
     for (int base = row_begin; base < row_end; base += IN_ROWS) {
         const int n = min(IN_ROWS, row_end - base);
         __syncthreads();
@@ -54,20 +56,34 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
                 for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
             }
             a.Z[(size_t)(base + i) * 64 + lane] = z;
-            s += z;
-            sq = fmaf(z, z, sq);
+            if (cnt == 0) z0 = z;
+            const float d = z - z0;
+            s += d;
+            sq = fmaf(d, d, sq);
+            ++cnt;
         }
     }
     if (a.part_sum) {
         red[wave][lane][0] = s;
         red[wave][lane][1] = sq;
+        red[wave][lane][2] = z0;
+        if (lane == 0) red_n[wave] = cnt;
         __syncthreads();
         if (wave == 0) {
-            const float ts = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
-            const float tq = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+            double n = 0.0, mean = 0.0, m2 = 0.0;
+            for (int w = 0; w < 4; ++w) {
+                const double nw = (double)red_n[w];
+                if (nw <= 0.0) continue;
+                const double s1 = red[w][lane][0], s2 = red[w][lane][1];
+                const double mw = (double)red[w][lane][2] + s1 / nw, m2w = s2 - s1 * s1 / nw;
+                const double nn = n + nw, delta = mw - mean;
+                mean += delta * nw / nn;
+                m2 += m2w + delta * delta * n * nw / nn;
+                n = nn;
+            }
             const size_t o = (size_t)(q * a.chunks + chunk) * 64 + lane;
-            a.part_sum[o] = ts;
-            a.part_sq[o] = tq;
+            a.part_sum[o] = (float)mean;
+            a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);
         }
     }
 }
@@ -82,45 +98,46 @@ int pw_input(const PwInput &a, hipStream_t st)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// bn_finalize: block = (slot, 64 channels) x 4 row groups; sums the per-chunk partials of the windows of the
-// slot in a fixed order in double, so results are bitwise reproducible run to run.
+// bn_finalize: block = (slot, 64 channels) x 4 groups; merges the per-chunk (mean, M2) partials of the slot's
+// windows with Chan's formula in double, in a fixed order: bitwise reproducible run to run.
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
 {
-    __shared__ double rs[4][64], rq[4][64];
-    __shared__ int rows_s;
+    __shared__ double rn[4][64], rmean[4][64], rm2[4][64];
     const int slot = blockIdx.x;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;     // windows q = slot, slot + n_slots, ...
-    double s = 0.0, sq = 0.0;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
     if (c < a.C) {
         const int total = per_slot * a.chunks;
         for (int e = g; e < total; e += 4) {
             const int q = slot + (e / a.chunks) * a.n_slots;
-            const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
-            s += (double)a.part_sum[o];
-            sq += (double)a.part_sq[o];
+            const int ch = e % a.chunks;
+            const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
+            if (rows <= 0) continue;
+            const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
+            const double nw = (double)rows, mw = (double)a.part_sum[o], m2w = (double)a.part_sq[o];
+            const double nn = n + nw, delta = mw - mean;
+            mean += delta * nw / nn;
+            m2 += m2w + delta * delta * n * nw / nn;
+            n = nn;
         }
     }
-    rs[g][cl] = s;
-    rq[g][cl] = sq;
-    if (threadIdx.x == 0) {
-        int rows = 0;
-        for (int i = 0; i < per_slot; ++i) {
-            const int q = slot + i * a.n_slots;
-            rows += a.win_off[q + 1] - a.win_off[q];
-        }
-        rows_s = rows;
-    }
+    rn[g][cl] = n;
+    rmean[g][cl] = mean;
+    rm2[g][cl] = m2;
     __syncthreads();
     if (g == 0 && c < a.C) {
-        const double n = (double)rows_s;
-        const double ts = (rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl]);
-        const double tq = (rq[0][cl] + rq[1][cl]) + (rq[2][cl] + rq[3][cl]);
-        const double mean = ts / n;
-        double var = tq / n - mean * mean;
-        if (var < 0.0) var = 0.0;
+        for (int k = 1; k < 4; ++k) {
+            const double nw = rn[k][cl];
+            if (nw <= 0.0) continue;
+            const double nn = n + nw, delta = rmean[k][cl] - mean;
+            mean += delta * nw / nn;
+            m2 += rm2[k][cl] + delta * delta * n * nw / nn;
+            n = nn;
+        }
+        const double var = n > 0.0 ? m2 / n : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
         const float sc = a.gamma[c] * invstd;
         const size_t o = (size_t)slot * a.C + c;
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
         if (a.invstd) a.invstd[o] = invstd;
         if (a.stat_mean) {
             a.stat_mean[o] = (float)mean;
-            a.stat_uvar[o] = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+            a.stat_uvar[o] = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
         }
     }
 }

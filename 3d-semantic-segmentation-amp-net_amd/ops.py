@@ -77,3 +77,48 @@ def encoder_forward(enc_params, enc_buffers, x, win_off, n_windows, total_rows, 
                                       _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
     _lib.check(rc, "ampnet_encoder_fwd_f32")
     return local, glob, feat_T, in_T
+
+
+def head_forward(head_params, head_buffers, gl, lo, centroids, win_off, mask, B, W, total_rows, max_rows,
+                 n_classes, train, drop_p, seed, ws, targets=None, class_w=None, want_preds=False):
+    """gl [B*W, 256] (row b*W+w), lo [total_rows, 64], centroids [B, W, 2], mask [B, W] bool/uint8 or None
+    -> (logits [B, C, P], preds [B, P] int64 or None, loss [2] (ce, sum of weights) or None).
+    See include/ampnet_hip.h: ampnet_head_fwd_f32."""
+    for t, name in ((gl, "gl"), (lo, "lo"), (centroids, "centroids")):
+        _lib.require_gpu(t, name)
+        if t.dtype != torch.float32:
+            raise _lib.AmpnetError(f"head_forward: {name} must be float32")
+    Q = B * W
+    if tuple(gl.shape) != (Q, P.GLOBAL_DIM) or tuple(lo.shape) != (total_rows, P.LOCAL_DIM) or tuple(centroids.shape) != (B, W, 2):
+        raise _lib.AmpnetError(f"head_forward: shapes gl {tuple(gl.shape)} lo {tuple(lo.shape)} centroids {tuple(centroids.shape)} "
+                               f"do not match B={B} W={W} rows={total_rows}")
+    dev = gl.device
+    gl, lo, centroids = gl.contiguous(), lo.contiguous(), centroids.contiguous()
+    m8 = None
+    if mask is not None:
+        m8 = mask.to(device=dev, dtype=torch.uint8).contiguous()
+        if tuple(m8.shape) != (B, W):
+            raise _lib.AmpnetError(f"head_forward: mask {tuple(m8.shape)} != [B={B}, W={W}]")
+    Pp = total_rows // B
+    L = _lib.lib()
+    L.ampnet_head_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_head_workspace_bytes(B, W, total_rows, max_rows, n_classes, int(train))
+    buf = ws.get(need, dev)
+    logits = torch.empty((B, n_classes, Pp), dtype=torch.float32, device=dev)
+    preds = torch.empty((B, Pp), dtype=torch.int64, device=dev) if want_preds else None
+    loss = None
+    tg = None
+    if targets is not None:
+        tg = targets.to(device=dev, dtype=torch.int64).contiguous()
+        if tuple(tg.shape) != (B, Pp):
+            raise _lib.AmpnetError(f"head_forward: targets {tuple(tg.shape)} != [B={B}, P={Pp}]")
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+    cw = class_w.to(device=dev, dtype=torch.float32).contiguous() if class_w is not None else None
+    with torch.cuda.device(dev):
+        rc = L.ampnet_head_fwd_f32(head_params.arr, head_buffers.arr, _lib.ptr(gl), _lib.ptr(lo), _lib.ptr(centroids),
+                                   _lib.ptr(win_off), _lib.ptr(m8), B, W, total_rows, max_rows, n_classes, int(train),
+                                   ctypes.c_float(drop_p), ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(logits),
+                                   _lib.ptr(tg), _lib.ptr(cw), _lib.ptr(preds), _lib.ptr(loss), _lib.ptr(buf),
+                                   ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_head_fwd_f32")
+    return logits, preds, loss

@@ -97,6 +97,29 @@ int ampnet_encoder_fwd_f32(const float *const *params_host, float *const *buffer
                            float *local, float *global_feat, float *feat_T, float *in_T, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- a4 (+a6 forward): attention head -------------------------------------------------------------
+ * replaces SegmentationWithAttention.forward (pointNet/model/pointnetAtt.py:176-209) and, optionally, the
+ * loss / prediction lines of train_loop (train_pointnet-attention.py:138,445-450).
+ *   gl         [B * W, 256]   window tokens, row q = b * W + w (the reference's gl_feats[w, b, :])
+ *   lo         [total_rows, 64] local features; sample b owns rows of windows b*W .. b*W + W - 1 back to back
+ *                             (the reference's lo_feats[b]); every sample has the same np_cluster list, so
+ *                             total_rows = B * P and window (b, w) has np_cluster[w] rows (win_off says so)
+ *   centroids  [B, W, 2]
+ *   key_pad_mask [B, W] bytes, non-zero = ignore that cluster token as a key; NULL = no mask (:189)
+ *   logits     [B, n_classes, P]                                                             (:207-209)
+ *   train != 0: batch statistics for bn_2 / bn_3 (over all B * P rows), running stats updated, dropout with
+ *              probability drop_p on the attention weights and after both ReLUs (:204-206) from the
+ *              counter-based generator keyed by `seed`; eval: running statistics, no dropout.
+ *   targets    [B, P] int64 (-1 = ignore), class_w [n_classes], preds [B, P] int64, loss_out [2]
+ *              (weighted-mean CE, sum of weights): all optional (NULL).                              */
+size_t ampnet_head_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes, int train);
+int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl,
+                        const float *lo, const float *centroids, const int32_t *win_off,
+                        const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
+                        int train, float drop_p, uint32_t seed, float *logits, const long long *targets,
+                        const float *class_w, long long *preds, float *loss_out, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,70 @@ def test_encoder_eval_ragged_windows_match_oracle(synth, params):
         _close(glob[i], gg[0], 5e-5, f"global window {i}")
         _close(ft[i], t[0], 5e-5, f"feat_T window {i}")
         r0 += n
+
+
+def _head_tables(synth, params, seed):
+    ops = sub("ops")
+    p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(seed, params.HEAD_PARAMS).items()}
+    b = {k: torch.from_numpy(v).cuda() for k, v in synth.make_buffers(seed, params.HEAD_BUFFERS).items()}
+    return ops, p, b, ops.PointerTable(params.HEAD_PARAMS, p, "head params"), ops.PointerTable(params.HEAD_BUFFERS, b, "head buffers")
+
+
+def _head_inputs(synth):
+    gl = synth.uniform(31, (3, 2, 256), 0.0, 2.0)            # [W, B, E] like the reference
+    lo = synth.uniform(32, (2, 768, 64), -1.0, 1.0)
+    cent = synth.uniform(33, (2, 3, 2), -1.0, 1.0)
+    return gl, lo, cent
+
+
+@pytest.mark.parametrize("case", ["uniform_masked", "ragged_nomask"])
+def test_head_eval_matches_reference_golden(golden, synth, params, case):
+    g = golden("head")
+    ops, p, b, pt, bt = _head_tables(synth, params, 2)
+    gl, lo, cent = _head_inputs(synth)
+    npc = [256, 256, 256] if case == "uniform_masked" else [100, 300, 368]
+    mask = torch.tensor([[False, False, True], [False, False, False]]) if case == "uniform_masked" else None
+    B, W = 2, 3
+    gld = torch.from_numpy(np.ascontiguousarray(gl.transpose(1, 0, 2)).reshape(B * W, 256)).cuda()    # row b*W+w
+    lod = torch.from_numpy(lo.reshape(-1, 64)).cuda()
+    off, total, mx = ops.window_offsets(npc * B, lod.device)
+    logits, _, _ = ops.head_forward(pt, bt, gld, lod, torch.from_numpy(cent).cuda(), off, mask, B, W, total, mx, 5,
+                                    False, 0.3, 0, ops.Workspace())
+    _close(logits, g[case], 1e-4, "logits")     # north_star bar: 1e-3
+
+
+def test_head_train_dropout_matches_oracle(synth, params):
+    """Train mode: batch statistics + the counter-based dropout, whose keep-masks the oracle restates bit for bit."""
+    ops, p, b, pt, bt = _head_tables(synth, params, 7)
+    B, W, npc = 4, 3, [160, 96, 224]
+    Pp = sum(npc)
+    gl = synth.uniform(41, (W, B, 256), 0.0, 2.0)
+    lo = synth.uniform(42, (B, Pp, 64), -1.0, 1.0)
+    cent = synth.uniform(43, (B, W, 2), -1.0, 1.0)
+    tg = synth.randint(44, (B, Pp), -1, 5)
+    mask = torch.tensor([[False, True, False]] + [[False] * 3] * 3)
+    drop_p, seed = 0.3, 1234
+    gld = torch.from_numpy(np.ascontiguousarray(gl.transpose(1, 0, 2)).reshape(B * W, 256)).cuda()
+    lod = torch.from_numpy(lo.reshape(-1, 64)).cuda()
+    off, total, mx = ops.window_offsets(npc * B, lod.device)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0])
+    logits, preds, loss = ops.head_forward(pt, bt, gld, lod, torch.from_numpy(cent).cuda(), off, mask, B, W, total, mx, 5,
+                                           True, drop_p, seed, ops.Workspace(), targets=torch.from_numpy(tg), class_w=cw,
+                                           want_preds=True)
+    op = {k: v.double() for k, v in torch_params(synth.make_params(7, params.HEAD_PARAMS)).items()}
+    ob = {k: v.double() for k, v in torch_params(synth.make_buffers(7, params.HEAD_BUFFERS)).items()}
+
+    def km(stream, n):
+        return torch.from_numpy(O.keep_mask(seed, stream, n, drop_p).astype(np.float64))
+    masks = {"att": km(0, B * 8 * W * W).reshape(B * 8, W, W),
+             "d2": km(1, B * Pp * 128).reshape(B, Pp, 128).transpose(1, 2),
+             "d3": km(2, B * Pp * 64).reshape(B, Pp, 64).transpose(1, 2)}
+    want = O.head(op, ob, torch.from_numpy(gl).double(), torch.from_numpy(lo).double(), torch.from_numpy(cent).double(),
+                  npc, mask, True, drop_p=drop_p, drop_masks=masks)
+    _close(logits, want.float(), 2e-4, "train logits")
+    ce, _ = O.loss_terms(want, torch.from_numpy(tg), torch.eye(64, dtype=torch.float64)[None])
+    assert abs(loss[0].item() - ce.item()) <= 2e-5 * max(1.0, abs(ce.item()))
+    pw = O.predictions(want).numpy()
+    assert (preds.cpu().numpy() != pw).mean() < 1e-3
+    for k in ob:
+        _close(b[k], ob[k].float(), 1e-4, k)
