@@ -1,0 +1,120 @@
+// loss.hip -- the loss recipe of train_pointnet-attention.py:138,445,463-467 outside the head kernel:
+//   reg = || I - F F^T ||_F over the whole [n, 64, 64] stack of feature transforms (forward and gradient),
+//   weighted cross-entropy gradient d(ce)/d(logits) for logits [B, C, P], targets [B, P] (-1 = ignore).
+#include "kernels.h"
+
+namespace ampnet {
+
+// one block per matrix: G = I - F F^T held in LDS; out_part[m] = sum G^2; optionally keeps G for the backward
+__global__ __launch_bounds__(256) void reg_fwd_kernel(const float *__restrict__ F, float *__restrict__ part, float *__restrict__ G)
+{
+    __shared__ float sF[64][65];
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < 4096; e += 256) sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
+    __syncthreads();
+    float acc = 0.f;
+    for (int e = tid; e < 4096; e += 256) {
+        const int i = e / 64, j = e % 64;
+        float d = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) d = fmaf(sF[i][k], sF[j][k], d);
+        const float g = (i == j ? 1.0f : 0.0f) - d;
+        if (G) G[(size_t)m * 4096 + e] = g;
+        acc = fmaf(g, g, acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) part[m] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void reg_finalize_kernel(const float *__restrict__ part, int n, float *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)part[i];
+        out[0] = (float)sqrt(s);
+    }
+}
+
+// dF += coef * d(reg)/dF,  d(reg)/dF = -2 G F / reg   (G symmetric)
+__global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ F, const float *__restrict__ G,
+                                                     const float *__restrict__ reg, float coef, float *__restrict__ dF)
+{
+    __shared__ float sF[64][65], sG[64][65];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < 4096; e += 256) {
+        sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
+        sG[e / 64][e % 64] = G[(size_t)m * 4096 + e];
+    }
+    __syncthreads();
+    const float r = reg[0];
+    const float k = r > 0.f ? -2.0f * coef / r : 0.f;
+    for (int e = tid; e < 4096; e += 256) {
+        const int i = e / 64, j = e % 64;
+        float d = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) d = fmaf(sG[i][l], sF[l][j], d);
+        dF[(size_t)m * 4096 + e] += k * d;
+    }
+}
+
+// dlogits[b, c, p] = gscale * w[t] / sum_w * (softmax(logits[b, :, p])[c] - [c == t]); 0 where t == -1
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float *__restrict__ logits, const long long *__restrict__ targets,
+                                                    const float *__restrict__ class_w, const float *__restrict__ loss2,
+                                                    float gscale, int B, int C, int P, float *__restrict__ dlogits)
+{
+    const size_t row = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (row >= (size_t)B * P) return;
+    const int b = (int)(row / P), p = (int)(row % P);
+    const long long t = targets[row];
+    float l[8];
+    float m = -__builtin_inff();
+    for (int c = 0; c < C; ++c) {
+        l[c] = logits[((size_t)b * C + c) * P + p];
+        m = fmaxf(m, l[c]);
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+        l[c] = expf(l[c] - m);
+        se += l[c];
+    }
+    const bool live = t >= 0 && t < C;
+    const float w = live ? (class_w ? class_w[t] : 1.0f) : 0.f;
+    const float k = live ? gscale * w / loss2[1] : 0.f;
+    for (int c = 0; c < C; ++c) dlogits[((size_t)b * C + c) * P + p] = k * (l[c] / se - (c == (int)t ? 1.0f : 0.0f));
+}
+
+}  // namespace ampnet
+
+using namespace ampnet;
+
+extern "C" int ampnet_reg_loss_fwd_f32(const float *feat_T, int n, float *reg_out, float *G, float *part, void *stream)
+{
+    AMPNET_REQUIRE(feat_T && reg_out && part && n >= 1, "ampnet_reg_loss_fwd_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(reg_fwd_kernel, dim3(n), dim3(256), 0, st, feat_T, part, G);
+    hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(64), 0, st, part, n, reg_out);
+    return check_launch("reg_loss_fwd");
+}
+
+extern "C" int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *reg, float coef, int n, float *d_feat_T,
+                                       void *stream)
+{
+    AMPNET_REQUIRE(feat_T && G && reg && d_feat_T && n >= 1, "ampnet_reg_loss_bwd_f32: bad arguments");
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T);
+    return check_launch("reg_loss_bwd");
+}
+
+extern "C" int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
+                                 float grad_scale, int B, int C, int P, float *dlogits, void *stream)
+{
+    AMPNET_REQUIRE(logits && targets && loss2 && dlogits, "ampnet_ce_bwd_f32: null pointer");
+    AMPNET_REQUIRE(B >= 1 && P >= 1 && C >= 1 && C <= 8, "ampnet_ce_bwd_f32: bad sizes");
+    const size_t rows = (size_t)B * P;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, logits, targets, class_w,
+                       loss2, grad_scale, B, C, P, dlogits);
+    return check_launch("ce_bwd_kernel");
+}

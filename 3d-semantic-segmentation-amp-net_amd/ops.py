@@ -122,3 +122,18 @@ def head_forward(head_params, head_buffers, gl, lo, centroids, win_off, mask, B,
                                    ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
     _lib.check(rc, "ampnet_head_fwd_f32")
     return logits, preds, loss
+
+
+def reg_loss(feat_T, keep_G=False):
+    """|| I - F F^T ||_F over the stack feat_T [n, 64, 64] -> device scalar tensor [1] (and G when keep_G)."""
+    _lib.require_gpu(feat_T, "feat_T")
+    f = feat_T.contiguous().float()
+    n = f.shape[0]
+    dev = f.device
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    part = torch.empty(n, dtype=torch.float32, device=dev)
+    G = torch.empty_like(f) if keep_G else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_reg_loss_fwd_f32(_lib.ptr(f), n, _lib.ptr(out), _lib.ptr(G), _lib.ptr(part), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_reg_loss_fwd_f32")
+    return (out, G) if keep_G else out

@@ -120,6 +120,18 @@ int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_h
                         const float *class_w, long long *preds, float *loss_out, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* ---- a6: loss recipe (train_pointnet-attention.py:138,445,463-467) ------------------------------------
+ * reg = || I - F F^T ||_F over the whole stack feat_T [n, 64, 64] (torch.norm of a 3-D tensor = Frobenius over
+ * all elements).  G [n, 64, 64] (optional) receives I - F F^T for the backward; part [n] is scratch.
+ * ampnet_reg_loss_bwd_f32:  d_feat_T += coef * d(reg)/d(feat_T).
+ * ampnet_ce_bwd_f32:        dlogits = grad_scale * d(ce)/d(logits) for the weighted-mean CE the head forward
+ *                           returned in loss2 = {ce, sum of weights} (ignore_index -1).                     */
+int ampnet_reg_loss_fwd_f32(const float *feat_T, int n, float *reg_out, float *G, float *part, void *stream);
+int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *reg, float coef, int n, float *d_feat_T,
+                            void *stream);
+int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
+                      float grad_scale, int B, int C, int P, float *dlogits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""End-to-end step parity on the GPU: the package's train_loop against what the reference's own train_loop
+returned on the same seeded batch (tests/golden/step.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import sub                           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class _NoOpt:
+    def zero_grad(self):
+        pass
+
+
+def _models(synth, params, dropout=0.3):
+    M = sub("pointNet.model.pointnetAtt")
+    enc = M.BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device="cuda")
+    att = M.SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, dropout=dropout, device="cuda")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(3, params.ENC_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(3, params.ENC_BUFFERS).items()})
+    r = enc.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.endswith("num_batches_tracked") for k in r.missing_keys)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(4, params.HEAD_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(4, params.HEAD_BUFFERS).items()})
+    r = att.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all(k.endswith("num_batches_tracked") for k in r.missing_keys)
+    return enc, att
+
+
+def _batch(golden, synth):
+    g = golden("step")
+    B, N, W = [int(v) for v in g["meta"]]
+    pc, tg, cent, _ = synth.sample_batch(41, B, N, max_w=W, w_real=[int(v) for v in g["w_real"]])
+    data = (torch.from_numpy(pc), torch.from_numpy(tg), [f"f{i}" for i in range(B)], torch.from_numpy(cent))
+    return g, data
+
+
+def test_state_dict_keys_match_reference(synth, params):
+    enc, att = _models(synth, params)
+    want = set(params.ENC_PARAMS) | set(params.ENC_BUFFERS) | {k.replace("running_mean", "num_batches_tracked") for k in params.ENC_BUFFERS if k.endswith("running_mean")}
+    assert set(enc.state_dict().keys()) == want
+    want = set(params.HEAD_PARAMS) | set(params.HEAD_BUFFERS) | {"bn_2.num_batches_tracked", "bn_3.num_batches_tracked"}
+    assert set(att.state_dict().keys()) == want
+    assert sum(p.numel() for p in enc.parameters()) == 883401 and sum(p.numel() for p in att.parameters()) == 317621
+
+
+def test_train_loop_eval_matches_reference(golden, synth, params):
+    S = sub("pointNet.amp_step")
+    enc, att = _models(synth, params)
+    g, data = _batch(golden, synth)
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
+    np.random.seed(777)
+    m, tpc, preds, _ = S.train_loop(data, _NoOpt(), _NoOpt(), ce, enc, att, None, "segmentation", False, 0, 0)
+    assert abs(m["ce_loss"].item() - g["eval_ce"].item()) <= 5e-5 * abs(g["eval_ce"].item())
+    assert abs(m["reg_loss"].item() - g["eval_reg"].item()) <= 5e-5 * abs(g["eval_reg"].item())
+    assert abs(m["loss"].item() - g["eval_loss"].item()) <= 5e-5 * abs(g["eval_loss"].item())
+    assert np.array_equal(tpc.numpy(), g["eval_targets"])
+    assert (preds.numpy() != g["eval_preds"]).mean() < 1e-3
+
+
+def test_reference_signature_forward_eval(golden, synth, params):
+    """BasePointNet.forward / SegmentationWithAttention.forward with the reference's own shapes and returns."""
+    enc, att = _models(synth, params)
+    enc.eval(); att.eval()
+    x = torch.from_numpy(synth.windows(21, 2, 256)).cuda()
+    with torch.no_grad():
+        out, ft = enc(x)
+    assert out.shape == (2, 256, 320) and ft.shape == (2, 64, 64)
+    assert torch.equal(out[:, 0, :256], out[:, 5, :256])
+    gl = torch.stack([out[:, 0, :-64]] * 3, 0)                       # [W, B, 256]
+    lo = torch.cat([out[:, :, -64:]] * 3, 1)                         # [B, 3 * 256, 64]
+    with torch.no_grad():
+        logits, zero = att(gl, lo, torch.zeros(2, 3, 2).cuda(), [256, 256, 256])
+    assert logits.shape == (2, 5, 768) and zero == 0
+    with pytest.raises(Exception):
+        enc(x.cpu())                                                 # no CPU fallback
