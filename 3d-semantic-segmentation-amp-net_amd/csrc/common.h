@@ -26,6 +26,15 @@ inline int check_launch(const char *what)
         if (!(cond)) return ::ampnet::fail(AMPNET_E_ARG, __VA_ARGS__); \
     } while (0)
 
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): off by default,
+// when on every instrumented launch is bracketed by two events; ampnet_profile_read() synchronises and sums.
+struct ProfScope {
+    ProfScope(const char *name, double flops, double bytes, hipStream_t st);
+    ~ProfScope();
+    int slot;
+    hipStream_t st;
+};
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1,5 +1,7 @@
 // core.hip -- error plumbing and version entry points of the C ABI (include/ampnet_hip.h).
 #include "common.h"
+#include <cstring>
+#include <vector>
 
 namespace ampnet {
 
@@ -18,7 +20,77 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// ---- event profiler --------------------------------------------------------------------------------
+namespace {
+struct ProfEntry {
+    char name[64];
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+}  // namespace
+
+ProfScope::ProfScope(const char *name, double flops, double bytes, hipStream_t s) : slot(-1), st(s)
+{
+    if (!g_prof_on) return;
+    ProfEntry e;
+    snprintf(e.name, sizeof(e.name), "%s", name);
+    e.flops = flops;
+    e.bytes = bytes;
+    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+    (void)hipEventRecord(e.e0, st);
+    g_prof.push_back(e);
+    slot = (int)g_prof.size() - 1;
+}
+
+ProfScope::~ProfScope()
+{
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].e1, st);
+}
+
 }  // namespace ampnet
+
+extern "C" int ampnet_profile_enable(int on)
+{
+    for (auto &e : ampnet::g_prof) {
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+    ampnet::g_prof.clear();
+    ampnet::g_prof_on = on != 0;
+    return AMPNET_OK;
+}
+
+// Aggregates the recorded launches by kernel name.  names: [max][64] chars; returns the number of rows written.
+extern "C" int ampnet_profile_read(int max_rows, char *names, double *ms, long long *calls, double *flops, double *bytes)
+{
+    using namespace ampnet;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AMPNET_E_LAUNCH, "ampnet_profile_read: device synchronize failed");
+    int n = 0;
+    for (auto &e : g_prof) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.e0, e.e1) != hipSuccess) continue;
+        int k = 0;
+        for (; k < n; ++k)
+            if (strncmp(names + 64 * k, e.name, 64) == 0) break;
+        if (k == n) {
+            if (n >= max_rows) continue;
+            memset(names + 64 * k, 0, 64);
+            snprintf(names + 64 * k, 64, "%s", e.name);
+            ms[k] = 0.0;
+            calls[k] = 0;
+            flops[k] = 0.0;
+            bytes[k] = 0.0;
+            ++n;
+        }
+        ms[k] += (double)t;
+        calls[k] += 1;
+        flops[k] += e.flops;
+        bytes[k] += e.bytes;
+    }
+    return n;
+}
 
 extern "C" int ampnet_abi_version(void) { return AMPNET_ABI_VERSION; }
 extern "C" const char *ampnet_last_error(void) { return ampnet::err_buf(); }

@@ -146,7 +146,7 @@ struct EncRun {
         g.Z = Z; g.ldz = cout; g.cout = cout;
         if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
         if (pool) { g.part_max = ws.part_max; g.part_min = ws.part_min; g.part_amax = ws.part_amax; g.part_amin = ws.part_amin; }
-        g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
         return g;
     }
     // FC layer on the pooled rows: n_slots windows of Q / n_slots rows (one window of Q rows in eval mode)
@@ -159,7 +159,7 @@ struct EncRun {
         g.n_slots = s.train ? s.n_slots : 1;
         g.Z = Z; g.ldz = ldz; g.cout = cout;
         if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = ws.fc_off; g.Q = s.n_slots; g.chunk_rows = s.fc_chunk_rows; g.chunks = s.fc_chunks;
+        g.win_off = ws.fc_off; g.Q = s.n_slots; g.chunk_rows = s.fc_chunk_rows; g.chunks = s.fc_chunks; g.rows_hint = s.Q;
         return g;
     }
     int finalize(int bn, bool fc) const

@@ -125,7 +125,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         g.A = A; g.lda = 256; g.cin = 256;
         g.W = Wm; g.ldw = ldw; g.bias = bias;
         g.Z = Z; g.ldz = cout; g.cout = cout;
-        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks;
+        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks; g.rows_hint = Q;
         return pw_gemm(g, st);
     };
     TRY(tok_gemm(ws.tok, P[HP_INPROJ_W], 256, P[HP_INPROJ_B], 768, ws.qkv));
@@ -153,7 +153,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         g.bias = ws.gbias; g.bias_win_stride = 128;
         g.Z = ws.z2; g.ldz = 128; g.cout = 128;
         if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
         if (tr) TRY(finalize(ws.bn2, HP_BN2_W, HP_BN2_B));
     }
@@ -165,7 +165,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
         g.Z = ws.z3; g.ldz = 64; g.cout = 64;
         if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks;
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
         if (tr) TRY(finalize(ws.bn3, HP_BN3_W, HP_BN3_B));
     }

@@ -42,6 +42,7 @@ struct PwGemm {
     int Q = 0;
     int chunk_rows = 512;
     int chunks = 1;                // cdiv(max window rows, chunk_rows)
+    long rows_hint = 0;            // total rows (profiling only: algorithmic flops / bytes of the launch)
 };
 int pw_gemm(const PwGemm &a, hipStream_t st);
 

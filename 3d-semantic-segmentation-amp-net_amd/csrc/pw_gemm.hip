@@ -317,6 +317,10 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
         attr_set = true;
     }
     dim3 grid(a.chunks, a.Q, cdiv(a.cout, CB));
+    char name[64];
+    snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "");
+    const double rows = (double)a.rows_hint;
+    ProfScope prof(name, 2.0 * rows * CIN * a.cout, rows * 4.0 * ((double)CIN * cdiv(a.cout, CB) + (a.Z ? a.cout : 0)), st);
     hipLaunchKernelGGL(kern, grid, dim3(PW_NW * 64), lds, st, a);
     return check_launch("pw_gemm_kernel");
 }

@@ -33,12 +33,22 @@ class PointerTable:
         self.arr = arr
 
 
+_OFF_CACHE = {}
+
+
 def window_offsets(np_cluster, device):
-    """[Q+1] int32 device prefix offsets from a list of window sizes."""
-    off = [0]
-    for n in np_cluster:
-        off.append(off[-1] + int(n))
-    return torch.tensor(off, dtype=torch.int32, device=device), off[-1], max(int(n) for n in np_cluster)
+    """[Q+1] int32 device prefix offsets from a list of window sizes (cached: the upload is a blocking copy)."""
+    key = (tuple(int(n) for n in np_cluster), str(device))
+    hit = _OFF_CACHE.get(key)
+    if hit is None:
+        off = [0]
+        for n in key[0]:
+            off.append(off[-1] + n)
+        if len(_OFF_CACHE) > 64:
+            _OFF_CACHE.clear()
+        hit = (torch.tensor(off, dtype=torch.int32, device=device), off[-1], max(key[0]))
+        _OFF_CACHE[key] = hit
+    return hit
 
 
 class Workspace:

@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- AMP-Net hot path on MI355X: synthetic ALS windows of 2048 points x 9 features.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd|train] [--batch B]
+
+One "step" = one pass of the hot path over one batch resident in HBM:
+  fwd   (BASELINE.json configs[1]): AMP-Net forward, eval mode, fp32, B=32 samples x W=9 windows x N=2048 points
+        -> logits + argmax (train_pointnet-attention.py train_loop(train=False) without the host legs).
+  train (BASELINE.json configs[2], when the backward path is built): forward + loss + backward + 2x Adam, B=64.
+For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); every rank processes
+its own batch (data parallel, weak scaling); in train mode gradients are all-reduced.
+Rank 0 prints ONE JSON line.  `value` = points/s over all ranks, inputs resident in HBM before the timed region.
+The roofline object comes from a SECOND pass of the same K steps with HIP events around every kernel launch
+(ampnet_profile_*), so that event recording does not sit inside the throughput number; both times are printed.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "3d-semantic-segmentation-amp-net_amd"
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec
+RIDGE = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
+N_POINTS, N_WIN = 2048, 9
+
+
+def sub(name=""):
+    return importlib.import_module(PKG + ("." + name if name else ""))
+
+
+def build_models(device, train):
+    synth, P = sub("synthetic"), sub("params")
+    M = sub("pointNet.model.pointnetAtt")
+    enc = M.BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device=device)
+    att = M.SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, device=device)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(3, P.ENC_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(3, P.ENC_BUFFERS).items()})
+    enc.load_state_dict(sd, strict=False)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(4, P.HEAD_PARAMS).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(4, P.HEAD_BUFFERS).items()})
+    att.load_state_dict(sd, strict=False)
+    enc.train(train)
+    att.train(train)
+    return enc, att
+
+
+def profile_read():
+    L = sub("_lib").lib()
+    n_max = 64
+    names = ctypes.create_string_buffer(64 * n_max)
+    ms = (ctypes.c_double * n_max)()
+    calls = (ctypes.c_longlong * n_max)()
+    flops = (ctypes.c_double * n_max)()
+    nbytes = (ctypes.c_double * n_max)()
+    n = L.ampnet_profile_read(n_max, names, ms, calls, flops, nbytes)
+    out = []
+    for i in range(max(n, 0)):
+        nm = names.raw[64 * i:64 * (i + 1)].split(b"\0")[0].decode()
+        out.append(dict(name=nm, ms=ms[i], calls=calls[i], flops=flops[i], bytes=nbytes[i]))
+    return out
+
+
+def roofline_from(rows):
+    if not rows:
+        return None
+    top = max(rows, key=lambda r: r["ms"])
+    per_ms = top["ms"] / top["calls"]
+    intensity = top["flops"] / max(top["bytes"], 1.0)
+    if intensity >= RIDGE:
+        ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
+        return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4), traffic=None, launch_ms=round(per_ms, 4),
+                    launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
+    ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None, launch_ms=round(per_ms, 4), launches=int(top["calls"]),
+                share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
+
+
+def cpu_baseline(mode, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on a bounded sample of the
+    same workload: B_cpu samples x 9 windows x 2048 points, eval forward (fwd) or forward+backward+Adam (train)."""
+    from oracle import ampnet_oracle as O
+    synth, P = sub("synthetic"), sub("params")
+    # the threads this process may actually run on (the GPU box gives a 16-CPU share of a 256-thread host)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("AMPNET_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    Bc = 2 if mode == "fwd" else 4
+    pc, tg, cent, _ = synth.sample_batch(7, Bc, N_POINTS, max_w=N_WIN)
+    ep = {k: torch.from_numpy(v) for k, v in synth.make_params(3, P.ENC_PARAMS).items()}
+    eb = {k: torch.from_numpy(v) for k, v in synth.make_buffers(3, P.ENC_BUFFERS).items()}
+    hp = {k: torch.from_numpy(v) for k, v in synth.make_params(4, P.HEAD_PARAMS).items()}
+    hb = {k: torch.from_numpy(v) for k, v in synth.make_buffers(4, P.HEAD_BUFFERS).items()}
+    pct, tgt, cet = torch.from_numpy(pc), torch.from_numpy(tg), torch.from_numpy(cent)
+    if mode == "train":
+        for d in (ep, hp):
+            for v in d.values():
+                v.requires_grad_(True)
+        state = {id(v): (torch.zeros_like(v), torch.zeros_like(v)) for d in (ep, hp) for v in d.values()}
+
+    def one(step):
+        if mode == "fwd":
+            with torch.no_grad():
+                lg, tpc, ft, _ = O.forward_windows(ep, eb, hp, hb, pct, tgt, cet, False, False)
+                O.predictions(lg)
+        else:
+            lg, tpc, ft, _ = O.forward_windows(ep, eb, hp, hb, pct, tgt, cet, True, True)
+            ce, reg = O.loss_terms(lg, tpc, ft)
+            for d in (ep, hp):
+                for v in d.values():
+                    v.grad = None
+            (ce + 0.001 * reg).backward()
+            with torch.no_grad():
+                for d in (ep, hp):
+                    for v in d.values():
+                        m, s = state[id(v)]
+                        O.adam_step(v, v.grad, m, s, step)
+
+    one(1)                                                # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        one(n + 2)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    dt = time.perf_counter() - t0
+    pts = n * Bc * N_WIN * N_POINTS
+    return dict(value=round(pts / dt, 1), unit="points/s", cores=cores, kind="port",
+                sample=f"{n} x ({Bc} samples x {N_WIN} windows x {N_POINTS} pts) {mode}, oracle torch-CPU fp32, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["fwd", "train", "auto"], default="auto")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    trainer_mod = None
+    try:
+        trainer_mod = sub("trainer")
+    except ModuleNotFoundError:
+        pass
+    mode = args.mode
+    if mode == "auto":
+        mode = "train" if trainer_mod is not None and getattr(trainer_mod, "READY", False) else "fwd"
+    B = args.batch or (64 if mode == "train" else 32)
+
+    synth = sub("synthetic")
+    S = sub("pointNet.amp_step")
+    enc, att = build_models(dev, train=(mode == "train"))
+    pc, tg, cent, _ = synth.sample_batch(100 + rank, B, N_POINTS, max_w=N_WIN)
+    x = torch.from_numpy(np.ascontiguousarray(pc.transpose(0, 3, 1, 2))).to(dev)          # [B, W, N, 9] resident in HBM
+    t = torch.from_numpy(np.ascontiguousarray(tg.transpose(0, 2, 1))).to(dev)
+    centd = torch.from_numpy(cent).to(dev)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device=dev)
+
+    if mode == "fwd":
+        def step():
+            with torch.no_grad():
+                return S.forward_batch(enc, att, x, t, centd, cw, want_loss=False, want_preds=True)
+    else:
+        tr = trainer_mod.Trainer(enc, att, lr=1e-3, class_w=cw, world_size=world)
+
+        def step():
+            return tr.step(x, t, centd)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # second pass with HIP events around every instrumented kernel (rank 0 only needs it, all ranks run it)
+    L = sub("_lib").lib()
+    L.ampnet_profile_enable(1)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt_prof = time.perf_counter() - t1
+    rows = profile_read()
+    L.ampnet_profile_enable(0)
+
+    if rank == 0:
+        pts_step = B * N_WIN * N_POINTS
+        value = world * pts_step * args.steps / dt
+        flop_pt = 413148 if mode == "fwd" else 1239444
+        out = {
+            "metric": "train points/sec + forward ms/window (N=2048)" if mode == "train" else "forward points/sec + forward ms/window (N=2048)",
+            "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
+                       + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
+                       "global_batch": B * world, "parallelism": f"dp{world}"},
+            "ms_per_window": round(dt / args.steps * 1e3 / (B * N_WIN), 5),
+            "model_tflops": round(value * flop_pt / 1e12, 2),
+            "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
+            "roofline": roofline_from(rows),
+            "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
+                                    tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))
+                               for r in rows], key=lambda r: -r["ms_per_step"])[:8],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mode)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,13 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- measurement hooks (bench.py roofline leg) --------------------------------------------------------
+ * ampnet_profile_enable(1) clears the table and brackets every instrumented kernel launch with two HIP events on
+ * the launch stream; ampnet_profile_read() synchronises the device and sums elapsed ms, launches, algorithmic
+ * flops and bytes per kernel name (names: max_rows x 64 chars).  Off by default: no events, no overhead.      */
+int ampnet_profile_enable(int on);
+int ampnet_profile_read(int max_rows, char *names, double *ms, long long *calls, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif
