@@ -1,0 +1,26 @@
+// bwd_misc.h -- small backward kernels (bwd_misc.hip); internal.
+#pragma once
+#include "kernels.h"
+
+namespace ampnet {
+
+int fc_act(const float *z, const float *s, const float *t, int rows, int C, int per, float *act, hipStream_t st);
+int fc_bn_bwd(const float *da, const float *z, const float *gamma, const float *scale, const float *shift, const float *mean,
+              const float *invstd, int n_slots, int per, int C, float *g, float *dgamma, float *dbeta, hipStream_t st);
+int colsum(const float *x, int rows, int C, float *out, hipStream_t st);
+int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st);
+
+struct PwInputWgrad {
+    const float *x = nullptr;                 // [rows, 9]
+    const float *dy = nullptr, *z = nullptr;  // [rows, 64]
+    const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, 64]
+    float *dWeff = nullptr;                   // [Q, 64, 9]
+    const int *win_off = nullptr;
+    int Q = 0, n_slots = 1;
+};
+int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st);
+int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
+                      float *dT, hipStream_t st);
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, hipStream_t st);   // dst[p(q)] = src[q]^T, 64 x 64
+
+}  // namespace ampnet

@@ -1,0 +1,407 @@
+// bwd_misc.hip -- the small backward kernels: BatchNorm-backward constants, MaxPool backward, a plain tiled
+// SGEMM for the [Q, <=4096] T-Net FC / attention projections, and the K<=12 input layers' weight gradients.
+#include "bwd_misc.h"
+
+namespace ampnet {
+
+// ----------------------------------------------------------------------------------------------------
+// bn_bwd_finalize: block = (slot, 64 channels) x 4 groups over the slot's partials, fixed order
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
+{
+    __shared__ double ra[4][64], rb[4][64];
+    __shared__ int rows_s;
+    const int slot = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    double sa = 0.0, sb = 0.0;
+    if (c < a.C) {
+        const int total = per_slot * a.chunks;
+        for (int e = g; e < total; e += 4) {
+            const int q = slot + (e / a.chunks) * a.n_slots;
+            const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
+            sa += (double)a.part_a[o];
+            sb += (double)a.part_b[o];
+        }
+    }
+    ra[g][cl] = sa;
+    rb[g][cl] = sb;
+    if (threadIdx.x == 0) {
+        int rows = 0;
+        for (int i = 0; i < per_slot; ++i) {
+            const int q = slot + i * a.n_slots;
+            rows += a.win_off[q + 1] - a.win_off[q];
+        }
+        rows_s = rows;
+    }
+    __syncthreads();
+    if (g == 0 && c < a.C) {
+        const double A = (ra[0][cl] + ra[1][cl]) + (ra[2][cl] + ra[3][cl]);
+        const double Bs = (rb[0][cl] + rb[1][cl]) + (rb[2][cl] + rb[3][cl]);
+        const double n = (double)rows_s;
+        const size_t o = (size_t)slot * a.C + c;
+        const double invstd = a.invstd[o], mean = a.mean[o];
+        const double s = (double)a.gamma[c] * invstd;
+        const double p2 = -s * invstd * Bs / n;
+        a.P1[o] = (float)s;
+        a.P2[o] = (float)p2;
+        a.P3[o] = (float)(-s * A / n - p2 * mean);
+        a.slot_ab[o * 2 + 0] = (float)A;
+        a.slot_ab[o * 2 + 1] = (float)Bs;
+    }
+}
+
+int bn_bwd_finalize(const BnBwdFinalize &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.part_a && a.part_b && a.win_off && a.gamma && a.mean && a.invstd && a.P1 && a.P2 && a.P3 && a.slot_ab, "bn_bwd_finalize: null pointer");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(256), 0, st, a);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+constexpr int MAX_BN_ITEMS = 24;
+struct BnGradArgs {
+    BnGradItem it[MAX_BN_ITEMS];
+    int n;
+};
+
+__global__ void bn_param_grads_kernel(BnGradArgs a)
+{
+    const BnGradItem it = a.it[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += blockDim.x) {
+        float db = 0.f, dg = 0.f;
+        for (int s = 0; s < it.n_slots; ++s) {
+            db += it.slot_ab[((size_t)s * it.C + c) * 2 + 0];
+            dg += it.slot_ab[((size_t)s * it.C + c) * 2 + 1];
+        }
+        it.dbeta[c] = db;
+        it.dgamma[c] = dg;
+    }
+}
+
+int bn_param_grads(const BnGradItem *items, int n, hipStream_t st)
+{
+    AMPNET_REQUIRE(n >= 1 && n <= MAX_BN_ITEMS, "bn_param_grads: %d items", n);
+    BnGradArgs a;
+    for (int i = 0; i < n; ++i) a.it[i] = items[i];
+    a.n = n;
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(n), dim3(256), 0, st, a);
+    return check_launch("bn_param_grads_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pool_bwd: block = (slot, 64 channels); loops the slot's windows (the only rows with a gradient are the
+// argmax rows), so the whole BatchNorm backward reduction of the pooled layer is B gathers per channel.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
+{
+    const int slot = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
+    if (c >= a.C) return;
+    const size_t so = (size_t)slot * a.C + c;
+    const float sc = a.scale[so], sh = a.shift[so], mean = a.mean[so], invstd = a.invstd[so];
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    double A = 0.0, Bs = 0.0;
+    int rows = 0;
+    for (int i = 0; i < per_slot; ++i) {
+        const int q = slot + i * a.n_slots;
+        rows += a.win_off[q + 1] - a.win_off[q];
+        const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+        const int row = a.arg[(size_t)q * a.C + c];
+        float d = 0.f;
+        if (row >= 0) {
+            const float zv = a.z[(size_t)row * a.C + c];
+            if (fmaf(zv, sc, sh) > 0.f) {
+                d = a.d_pooled[(size_t)prow * a.C + c];
+                A += (double)d;
+                Bs += (double)d * (double)((zv - mean) * invstd);
+            }
+        }
+        a.dpm[(size_t)prow * a.C + c] = d;
+    }
+    const double n = (double)rows;
+    const double gamma_invstd = (double)sc;      // scale = gamma * invstd
+    const double p2 = -gamma_invstd * (double)invstd * Bs / n;
+    a.P1[so] = sc;
+    a.P2[so] = (float)p2;
+    a.P3[so] = (float)(-gamma_invstd * A / n - p2 * (double)mean);
+    a.slot_ab[so * 2 + 0] = (float)A;
+    a.slot_ab[so * 2 + 1] = (float)Bs;
+}
+
+int pool_bwd(const PoolBwd &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.d_pooled && a.arg && a.z && a.scale && a.shift && a.mean && a.invstd && a.win_off && a.dpm && a.P1 && a.P2 && a.P3 && a.slot_ab, "pool_bwd: null pointer");
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64), 0, st, a);
+    return check_launch("pool_bwd_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// sgemm_small: 64 x 64 tile, 16-deep LDS slices, 4 x 4 outputs per thread (VALU fp32).
+// ----------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_small_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                         const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int accumulate)
+{
+    __shared__ float sA[16][65], sB[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            int m, k;
+            if (TA) { m = e % 64; k = e / 64; } else { k = e % 16; m = e / 16; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+            sA[k][m] = v;
+        }
+        for (int e = tid; e < 64 * 16; e += 256) {
+            int n, k;
+            if (TB) { k = e % 16; n = e / 16; } else { n = e % 64; k = e / 64; }
+            const int gn = n0 + n, gk = k0 + k;
+            float v = 0.f;
+            if (gn < N && gk < K) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+            sB[k][n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = sA[k][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = sB[k][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty + 16 * i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx + 16 * j;
+            if (gm < M && gn < N) {
+                float *d = C + (size_t)gm * ldc + gn;
+                *d = accumulate ? *d + acc[i][j] : acc[i][j];
+            }
+        }
+    }
+}
+
+int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                int accumulate, hipStream_t st)
+{
+    AMPNET_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1, "sgemm_small: bad arguments");
+    dim3 grid(cdiv(N, 64), cdiv(M, 64));
+    char name[64];
+    snprintf(name, sizeof(name), "sgemm_small");
+    ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), st);
+    if (transA && transB) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else if (transA) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else if (transB) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    return check_launch("sgemm_small_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// FC-layer helpers on [rows, C] with rows grouped in n_slots contiguous blocks of `per` rows
+// ----------------------------------------------------------------------------------------------------
+__global__ void fc_act_kernel(const float *__restrict__ z, const float *__restrict__ s, const float *__restrict__ t, int rows, int C,
+                              int per, float *__restrict__ act)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * C) return;
+    const int row = (int)(i / C), c = (int)(i % C);
+    const size_t so = (size_t)(row / per) * C + c;
+    act[i] = fmaxf(fmaf(z[i], s[so], t[so]), 0.f);
+}
+
+int fc_act(const float *z, const float *s, const float *t, int rows, int C, int per, float *act, hipStream_t st)
+{
+    const size_t n = (size_t)rows * C;
+    hipLaunchKernelGGL(fc_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, s, t, rows, C, per, act);
+    return check_launch("fc_act_kernel");
+}
+
+// da [rows, C] = grad wrt relu(bn(z)); per (slot, channel): full BatchNorm backward over the slot's `per` rows
+__global__ __launch_bounds__(64) void fc_bn_bwd_kernel(const float *__restrict__ da, const float *__restrict__ z, const float *__restrict__ gamma,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd, int n_slots, int per,
+                                                      int C, float *__restrict__ g, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float dg = 0.f, db = 0.f;
+    for (int s = 0; s < n_slots; ++s) {
+        const size_t so = (size_t)s * C + c;
+        const float sc = scale[so], sh = shift[so], mu = mean[so], is = invstd[so];
+        double A = 0.0, Bs = 0.0;
+        for (int i = 0; i < per; ++i) {
+            const size_t o = (size_t)(s * per + i) * C + c;
+            const float zv = z[o];
+            const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
+            A += (double)dy;
+            Bs += (double)dy * (double)((zv - mu) * is);
+        }
+        const float an = (float)(A / per), bn = (float)(Bs / per);
+        for (int i = 0; i < per; ++i) {
+            const size_t o = (size_t)(s * per + i) * C + c;
+            const float zv = z[o];
+            const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
+            g[o] = sc * (dy - an - (zv - mu) * is * bn);
+        }
+        db += (float)A;
+        dg += (float)Bs;
+    }
+    dgamma[c] = dg;
+    dbeta[c] = db;
+}
+
+int fc_bn_bwd(const float *da, const float *z, const float *gamma, const float *scale, const float *shift, const float *mean,
+              const float *invstd, int n_slots, int per, int C, float *g, float *dgamma, float *dbeta, hipStream_t st)
+{
+    hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, da, z, gamma, scale, shift, mean, invstd, n_slots, per, C, g,
+                       dgamma, dbeta);
+    return check_launch("fc_bn_bwd_kernel");
+}
+
+__global__ void colsum_kernel(const float *__restrict__ x, int rows, int C, float *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * C + c];
+    out[c] = s;
+}
+
+int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, rows, C, out);
+    return check_launch("colsum_kernel");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// input layers (K = 3 / 9): per-window dWeff[q][c][f] = sum_rows g[row][c] * x[row][f], lane = channel c
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
+{
+    __shared__ float sx[256 * 9];
+    __shared__ float red[4][64][9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int row_begin = a.win_off[q], row_end = a.win_off[q + 1];
+    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+    const float p1 = a.P1[(size_t)slot * 64 + lane], p2 = a.P2[(size_t)slot * 64 + lane], p3 = a.P3[(size_t)slot * 64 + lane];
+    float acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f) acc[f] = 0.f;
+    for (int base = row_begin; base < row_end; base += 256) {
+        const int n = min(256, row_end - base);
+        __syncthreads();
+        for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
+        __syncthreads();
+        for (int i = wave; i < n; i += 4) {
+            const size_t o = (size_t)(base + i) * 64 + lane;
+            const float g = fmaf(a.dy[o], p1, fmaf(a.z[o], p2, p3));
+#pragma unroll
+            for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, sx[i * 9 + f], acc[f]);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 9; ++f) red[wave][lane][f] = acc[f];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int f = 0; f < 9; ++f)
+            a.dWeff[((size_t)q * 64 + lane) * 9 + f] = (red[0][lane][f] + red[1][lane][f]) + (red[2][lane][f] + red[3][lane][f]);
+    }
+}
+
+int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.x && a.dy && a.z && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
+    hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(256), 0, st, a);
+    return check_launch("pw_input_wgrad_kernel");
+}
+
+// mode 0 (T-Net conv_1 on xyz): dW[c][f] = sum_q dWeff[q][c][f], f < 3
+// mode 1 (encoder conv_1):      dW[c][3+f] = sum_q dWeff[q][c][f];  dW[c][d] = sum_q sum_i T[p(q)][i][d] * dWeff[q][c][i];
+//                               dT[p(q)][i][d] = sum_c dWeff[q][c][i] * W[c][d]
+__global__ __launch_bounds__(64) void input_param_grads_kernel(const float *__restrict__ dWeff, const float *__restrict__ W,
+                                                              const float *__restrict__ T, int Q, int n_slots, int slot_major, int mode,
+                                                              float *__restrict__ dW, float *__restrict__ dT)
+{
+    const int c = threadIdx.x;       // channel
+    if (blockIdx.x == 0) {
+        if (mode == 0) {
+            float s[3] = {0.f, 0.f, 0.f};
+            for (int q = 0; q < Q; ++q)
+                for (int f = 0; f < 3; ++f) s[f] += dWeff[((size_t)q * 64 + c) * 9 + f];
+            for (int f = 0; f < 3; ++f) dW[c * 3 + f] = s[f];
+        } else {
+            float s[12] = {};
+            for (int q = 0; q < Q; ++q) {
+                const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
+                const float *e = dWeff + ((size_t)q * 64 + c) * 9;
+                for (int f = 0; f < 9; ++f) s[3 + f] += e[f];
+                for (int d = 0; d < 3; ++d) s[d] += T[p * 9 + 0 * 3 + d] * e[0] + T[p * 9 + 1 * 3 + d] * e[1] + T[p * 9 + 2 * 3 + d] * e[2];
+            }
+            for (int f = 0; f < 12; ++f) dW[c * 12 + f] = s[f];
+        }
+    } else if (mode == 1) {
+        // blocks 1..: dT for windows, one (q, i, d) per thread
+        const int idx = (blockIdx.x - 1) * 64 + threadIdx.x;
+        if (idx >= Q * 9) return;
+        const int q = idx / 9, i = (idx % 9) / 3, d = idx % 3;
+        const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
+        float s = 0.f;
+        for (int cc = 0; cc < 64; ++cc) s = fmaf(dWeff[((size_t)q * 64 + cc) * 9 + i], W[cc * 12 + d], s);
+        dT[p * 9 + i * 3 + d] = s;
+    }
+}
+
+int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
+                      float *dT, hipStream_t st)
+{
+    const int blocks = 1 + (mode == 1 ? cdiv(Q * 9, 64) : 0);
+    hipLaunchKernelGGL(input_param_grads_kernel, dim3(blocks), dim3(64), 0, st, dWeff, W, T, Q, n_slots, slot_major, mode, dW, dT);
+    return check_launch("input_param_grads_kernel");
+}
+
+__global__ void axpy_kernel(const float *__restrict__ x, float alpha, size_t n, float *__restrict__ y)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, alpha, n, y);
+    return check_launch("axpy_kernel");
+}
+
+// masked pooled gradient for FC inputs: nothing to do (pool_bwd handles the ReLU of the pooled layer)
+
+}  // namespace ampnet
+
+namespace ampnet {
+// dst[p(q)] = src[q]^T with p(q) the slot-major row of window q
+__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots)
+{
+    __shared__ float t[64][65];
+    const int q = blockIdx.x;
+    const size_t p = (size_t)(q % n_slots) * (Q / n_slots) + q / n_slots;
+    for (int e = threadIdx.x; e < 4096; e += 256) t[e / 64][e % 64] = src[(size_t)q * 4096 + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) dst[p * 4096 + e] = t[e % 64][e / 64];
+}
+
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, hipStream_t st)
+{
+    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots);
+    return check_launch("transpose64_kernel");
+}
+}  // namespace ampnet

@@ -1,0 +1,330 @@
+// encoder_bwd.hip -- C ABI: ampnet_encoder_bwd_f32 = autograd backward of BasePointNet.forward for all windows
+// of a step (the reference: loss.backward() at train_pointnet-attention.py:467 through pointnetAtt.py:80-112).
+//
+// Walks the forward launch sequence of encoder.hip in reverse.  Per BatchNorm'ed layer l (reverse order):
+//     [pool_bwd | bn_bwd_finalize]  ->  pw_wgrad(l) + reduce_windows  ->  pw_dgrad(l)  -> next layer's finalize
+// using only what the train-mode forward left in its workspace (pre-BatchNorm z, batch mean / invstd / affine,
+// argmax rows) plus two ping-pong dy buffers.  Train mode only (batch statistics).
+#include "bwd_misc.h"
+#include "encoder.h"
+
+namespace ampnet {
+namespace {
+
+struct BnBwdSlot {
+    float *P1, *P2, *P3, *slot_ab;   // [n_slots, C] x3, [n_slots, C, 2]
+};
+
+struct EncBwdWs {
+    float *dyA, *dyB;          // [R, 128] ping-pong
+    float *d_local, *d_h;      // [R, 64]
+    float *wpart, *dbpart;     // [Q, 256 * 128], [Q, 256]
+    float *dpm;                // [Q, 256] masked pooled gradient
+    float *a1, *a2, *da2, *g2, *da1, *g1, *d_pool;   // FC: [Q,256] [Q,128] [Q,128] [Q,128] [Q,256] [Q,256] [Q,256]
+    float *dT64, *dT64t;       // [Q, 4096]
+    float *dWeff, *dT3;        // [Q, 576], [Q, 12]
+    BnBwdSlot bn[BN_ENC_COUNT];
+    size_t bytes;
+};
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static const int kBnC2[BN_ENC_COUNT] = {64, 128, 256, 256, 128, 64, 64, 64, 128, 256, 256, 128, 64, 128, 128, 256};
+
+void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
+{
+    Carver c{reinterpret_cast<char *>(base)};
+    const size_t R = (size_t)s.R, Q = (size_t)s.Q;
+    w.dyA = c.take<float>(R * 128);
+    w.dyB = c.take<float>(R * 128);
+    w.d_local = c.take<float>(R * 64);
+    w.d_h = c.take<float>(R * 64);
+    w.wpart = c.take<float>(Q * 256 * 128);
+    w.dbpart = c.take<float>(Q * 256);
+    w.dpm = c.take<float>(Q * 256);
+    w.a1 = c.take<float>(Q * 256);
+    w.a2 = c.take<float>(Q * 128);
+    w.da2 = c.take<float>(Q * 128);
+    w.g2 = c.take<float>(Q * 128);
+    w.da1 = c.take<float>(Q * 256);
+    w.g1 = c.take<float>(Q * 256);
+    w.d_pool = c.take<float>(Q * 256);
+    w.dT64 = c.take<float>(Q * 4096);
+    w.dT64t = c.take<float>(Q * 4096);
+    w.dWeff = c.take<float>(Q * 576);
+    w.dT3 = c.take<float>(Q * 12);
+    for (int i = 0; i < BN_ENC_COUNT; ++i) {
+        const size_t n = (size_t)s.n_slots * kBnC2[i];
+        w.bn[i].P1 = c.take<float>(n);
+        w.bn[i].P2 = c.take<float>(n);
+        w.bn[i].P3 = c.take<float>(n);
+        w.bn[i].slot_ab = c.take<float>(2 * n);
+    }
+    w.bytes = align_up(c.off, 256);
+}
+
+#define TRY(x)                            \
+    do {                                  \
+        int rc_ = (x);                    \
+        if (rc_ != AMPNET_OK) return rc_; \
+    } while (0)
+
+struct EncBwd {
+    hipStream_t st;
+    EncShape s;
+    EncWs f;          // forward workspace (saved activations)
+    EncBwdWs b;
+    const float *const *P;
+    float *const *G;
+    const int *win_off;
+    const float *gamma[BN_ENC_COUNT];
+
+    GradSrc dense(const float *dy, const float *z, int bn, int C) const
+    {
+        GradSrc g;
+        g.dy = dy; g.z = z; g.C = C;
+        if (bn >= 0) { g.P1 = b.bn[bn].P1; g.P2 = b.bn[bn].P2; g.P3 = b.bn[bn].P3; }
+        return g;
+    }
+    GradSrc sparse(const int *arg, const float *dpm, int slot_major, const float *z, int bn) const
+    {
+        GradSrc g;
+        g.arg = arg; g.dpool = dpm; g.dpool_slot_major = slot_major; g.z = z; g.C = 256;
+        g.P1 = b.bn[bn].P1; g.P2 = b.bn[bn].P2; g.P3 = b.bn[bn].P3;
+        return g;
+    }
+    ActSrc act(const float *z, int bn, int C) const
+    {
+        ActSrc a;
+        a.z = z; a.C = C;
+        if (bn >= 0) { a.s = f.bn[bn].scale; a.t = f.bn[bn].shift; }
+        return a;
+    }
+    // dW[cx][cy] of a shared weight: per-window partials then ordered reduction
+    int wgrad(const GradSrc &x, const ActSrc &y, float *dW) const
+    {
+        PwWgrad w;
+        w.x = x; w.y = y; w.dWpart = b.wpart; w.ldp = y.C;
+        w.win_off = win_off; w.Q = s.Q; w.n_slots = s.n_slots; w.rows_hint = s.R;
+        TRY(pw_wgrad(w, st));
+        return reduce_windows(b.wpart, s.Q, (long)x.C * y.C, x.C, y.C, y.C, dW, y.C, 0, st);
+    }
+    // dy of layer `prev_bn` (masked) + its BatchNorm-backward partial sums, then that layer's constants
+    int dgrad(const GradSrc &g, const float *W, int ldw, const float *prev_z, int prev_bn, int cp, const float *add, float *out) const
+    {
+        PwDgrad d;
+        d.g = g; d.W = W; d.ldw = ldw; d.add = add; d.out = out; d.cp = cp;
+        if (prev_z) {
+            d.prev = act(prev_z, prev_bn, cp);
+            d.prev_mean = f.bn[prev_bn].mean; d.prev_invstd = f.bn[prev_bn].invstd;
+            d.part_a = f.part_sum; d.part_b = f.part_sq;
+        }
+        d.win_off = win_off; d.Q = s.Q; d.n_slots = s.n_slots; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = s.R;
+        TRY(pw_dgrad(d, st));
+        if (prev_z) {
+            BnBwdFinalize fz;
+            fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
+            fz.Q = s.Q; fz.chunks = s.chunks; fz.n_slots = s.n_slots; fz.C = cp;
+            fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
+            fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
+            TRY(bn_bwd_finalize(fz, st));
+        }
+        return AMPNET_OK;
+    }
+    int pool(const float *d_pooled, int slot_major, const int *arg, const float *z, int bn) const
+    {
+        PoolBwd p;
+        p.d_pooled = d_pooled; p.slot_major = slot_major; p.arg = arg; p.z = z;
+        p.scale = f.bn[bn].scale; p.shift = f.bn[bn].shift; p.mean = f.bn[bn].mean; p.invstd = f.bn[bn].invstd;
+        p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.C = 256;
+        p.dpm = b.dpm; p.P1 = b.bn[bn].P1; p.P2 = b.bn[bn].P2; p.P3 = b.bn[bn].P3; p.slot_ab = b.bn[bn].slot_ab;
+        return pool_bwd(p, st);
+    }
+
+    // T-Net FC head backward: g3 [Q, kk] (slot-major rows) -> parameter grads, d_pool [Q, 256]
+    int tnet_fc_bwd(int pbase, int bn0, const float *g3, int kk, const float *pooled, const float *zf1, const float *zf2) const
+    {
+        const int Q = s.Q, per = s.fc_rows, ns = s.n_slots;
+        TRY(fc_act(zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, Q, 256, per, b.a1, st));
+        TRY(fc_act(zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, Q, 128, per, b.a2, st));
+        // fc_3: z3 = a2 W3^T + b3
+        TRY(sgemm_small(1, 0, kk, 128, Q, g3, kk, b.a2, 128, G[pbase + TP_FC3_W], 128, 0, st));
+        TRY(colsum(g3, Q, kk, G[pbase + TP_FC3_B], st));
+        TRY(sgemm_small(0, 0, Q, 128, kk, g3, kk, P[pbase + TP_FC3_W], 128, b.da2, 128, 0, st));
+        TRY(fc_bn_bwd(b.da2, zf2, P[pbase + TP_BN5_W], f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per,
+                      128, b.g2, G[pbase + TP_BN5_W], G[pbase + TP_BN5_B], st));
+        // fc_2
+        TRY(sgemm_small(1, 0, 128, 256, Q, b.g2, 128, b.a1, 256, G[pbase + TP_FC2], 256, 0, st));
+        TRY(sgemm_small(0, 0, Q, 256, 128, b.g2, 128, P[pbase + TP_FC2], 256, b.da1, 256, 0, st));
+        TRY(fc_bn_bwd(b.da1, zf1, P[pbase + TP_BN4_W], f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per,
+                      256, b.g1, G[pbase + TP_BN4_W], G[pbase + TP_BN4_B], st));
+        // fc_1 on the pooled features
+        TRY(sgemm_small(1, 0, 256, 256, Q, b.g1, 256, pooled, 256, G[pbase + TP_FC1], 256, 0, st));
+        TRY(sgemm_small(0, 0, Q, 256, 256, b.g1, 256, P[pbase + TP_FC1], 256, b.d_pool, 256, 0, st));
+        return AMPNET_OK;
+    }
+};
+
+}  // namespace
+}  // namespace ampnet
+
+using namespace ampnet;
+
+extern "C" size_t ampnet_encoder_bwd_workspace_bytes(int Q, int n_slots, int total_rows, int max_rows)
+{
+    if (Q < 1 || n_slots < 1 || total_rows < 1 || max_rows < 1) return 0;
+    EncBwdWs w;
+    enc_bwd_carve(enc_shape(Q, n_slots, total_rows, max_rows, 1), nullptr, w);
+    return w.bytes;
+}
+
+extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *const *grads_host, const float *x,
+                                      const int32_t *win_off, int Q, int n_slots, int total_rows, int max_rows,
+                                      const float *local, const float *d_local, const float *d_global, const float *d_feat_T, const float *feat_T,
+                                      void *fwd_workspace, size_t fwd_workspace_bytes, void *bwd_workspace,
+                                      size_t bwd_workspace_bytes, void *stream)
+{
+    AMPNET_REQUIRE(params_host && grads_host && x && win_off && local && d_global && feat_T && fwd_workspace && bwd_workspace, "ampnet_encoder_bwd_f32: null pointer");
+    AMPNET_REQUIRE(Q >= 1 && n_slots >= 1 && Q % n_slots == 0, "ampnet_encoder_bwd_f32: Q=%d n_slots=%d", Q, n_slots);
+    EncBwd e;
+    e.st = (hipStream_t)stream;
+    e.s = enc_shape(Q, n_slots, total_rows, max_rows, 1);
+    enc_carve(e.s, fwd_workspace, e.f);
+    enc_bwd_carve(e.s, bwd_workspace, e.b);
+    if (e.f.bytes > fwd_workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_encoder_bwd_f32: forward workspace %zu B < %zu B", fwd_workspace_bytes, e.f.bytes);
+    if (e.b.bytes > bwd_workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_encoder_bwd_f32: backward workspace %zu B < %zu B", bwd_workspace_bytes, e.b.bytes);
+    e.P = params_host;
+    e.G = grads_host;
+    e.win_off = win_off;
+    const float *const *P = params_host;
+    float *const *G = grads_host;
+    for (int i = 0; i < 5; ++i) {
+        e.gamma[BN_T1 + i] = P[EP_IT + TP_BN1_W + 2 * i];
+        e.gamma[BN_F1 + i] = P[EP_FT + TP_BN1_W + 2 * i];
+    }
+    {
+        const int ids[6] = {BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};
+        for (int i = 0; i < 6; ++i) e.gamma[ids[i]] = P[EP_BN1_W + 2 * i];
+    }
+    const EncWs &f = e.f;
+    const EncBwdWs &b = e.b;
+    hipStream_t st = e.st;
+
+    // ---- conv_6 .. conv_3 --------------------------------------------------------------------------
+    TRY(e.pool(d_global, 0, f.arg_c, f.z_c6, BN_C6));
+    {
+        const GradSrc g6 = e.sparse(f.arg_c, b.dpm, 0, f.z_c6, BN_C6);
+        TRY(e.wgrad(g6, e.act(f.z_c5, BN_C5, 128), G[EP_CONV6]));
+        TRY(e.dgrad(g6, P[EP_CONV6], 128, f.z_c5, BN_C5, 128, nullptr, b.dyA));
+    }
+    {
+        const GradSrc g5 = e.dense(b.dyA, f.z_c5, BN_C5, 128);
+        TRY(e.wgrad(g5, e.act(f.z_c4, BN_C4, 128), G[EP_CONV5]));
+        TRY(e.dgrad(g5, P[EP_CONV5], 128, f.z_c4, BN_C4, 128, nullptr, b.dyB));
+    }
+    {
+        const GradSrc g4 = e.dense(b.dyB, f.z_c4, BN_C4, 128);
+        TRY(e.wgrad(g4, e.act(f.z_c3, BN_C3, 64), G[EP_CONV4]));
+        TRY(e.dgrad(g4, P[EP_CONV4], 64, f.z_c3, BN_C3, 64, nullptr, b.dyA));
+    }
+    {
+        // conv_3 reads `local` (the torch.bmm output, not activated); the head's gradient d_local joins here
+        const GradSrc g3 = e.dense(b.dyA, f.z_c3, BN_C3, 64);
+        ActSrc yl;
+        yl.z = local; yl.C = 64;
+        TRY(e.wgrad(g3, yl, G[EP_CONV3]));
+        TRY(e.dgrad(g3, P[EP_CONV3], 64, nullptr, -1, 64, d_local, b.d_local));
+    }
+    // ---- local = h x T64[window]: dT64 (per window, no reduction) and d_h ---------------------------------
+    {
+        PwWgrad w;                                   // dT^T[j][k] = sum_rows d_local[row][j] * h[row][k]
+        w.x = e.dense(b.d_local, nullptr, -1, 64);
+        w.y = e.act(f.z_c2, BN_C2, 64);
+        w.dWpart = b.dT64t; w.ldp = 64;
+        w.win_off = win_off; w.Q = Q; w.n_slots = n_slots; w.rows_hint = total_rows;
+        TRY(pw_wgrad(w, st));
+        // window q's matrix belongs at the slot-major row the forward used for feat_T
+        TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, st));
+        if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
+        PwDgrad d;                                   // d_h[row][k] = sum_j d_local[row][j] * T[k][j]
+        d.g = e.dense(b.d_local, nullptr, -1, 64);
+        d.W = feat_T; d.w_win_stride = 4096; d.perwin_slot_major = 1;
+        d.out = b.d_h; d.cp = 64;
+        d.win_off = win_off; d.Q = Q; d.n_slots = n_slots; d.chunk_rows = e.s.chunk_rows; d.chunks = e.s.chunks; d.rows_hint = total_rows;
+        TRY(pw_dgrad(d, st));
+    }
+    // ---- feature T-Net ---------------------------------------------------------------------------------------
+    TRY(e.tnet_fc_bwd(EP_FT, BN_F1, b.dT64, 4096, f.pool_f, f.z_ff1, f.z_ff2));
+    TRY(e.pool(b.d_pool, 1, f.arg_f, f.z_f3, BN_F3));
+    {
+        const GradSrc g = e.sparse(f.arg_f, b.dpm, 1, f.z_f3, BN_F3);
+        TRY(e.wgrad(g, e.act(f.z_f2, BN_F2, 128), G[EP_FT + TP_CONV3]));
+        TRY(e.dgrad(g, P[EP_FT + TP_CONV3], 128, f.z_f2, BN_F2, 128, nullptr, b.dyA));
+    }
+    {
+        const GradSrc g = e.dense(b.dyA, f.z_f2, BN_F2, 128);
+        TRY(e.wgrad(g, e.act(f.z_f1, BN_F1, 64), G[EP_FT + TP_CONV2]));
+        TRY(e.dgrad(g, P[EP_FT + TP_CONV2], 64, f.z_f1, BN_F1, 64, nullptr, b.dyB));
+    }
+    {
+        const GradSrc g = e.dense(b.dyB, f.z_f1, BN_F1, 64);
+        TRY(e.wgrad(g, e.act(f.z_c2, BN_C2, 64), G[EP_FT + TP_CONV1]));
+        TRY(e.dgrad(g, P[EP_FT + TP_CONV1], 64, f.z_c2, BN_C2, 64, b.d_h, b.dyA));      // + the bmm path into h
+    }
+    // ---- conv_2, conv_1 -----------------------------------------------------------------------------------------
+    {
+        const GradSrc g = e.dense(b.dyA, f.z_c2, BN_C2, 64);
+        TRY(e.wgrad(g, e.act(f.z_c1, BN_C1, 64), G[EP_CONV2]));
+        TRY(e.dgrad(g, P[EP_CONV2], 64, f.z_c1, BN_C1, 64, nullptr, b.dyB));
+    }
+    {
+        PwInputWgrad w;
+        w.x = x; w.dy = b.dyB; w.z = f.z_c1;
+        w.P1 = b.bn[BN_C1].P1; w.P2 = b.bn[BN_C1].P2; w.P3 = b.bn[BN_C1].P3;
+        w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
+        TRY(pw_input_wgrad(w, st));
+        TRY(input_param_grads(b.dWeff, P[EP_CONV1], f.T3, Q, n_slots, 1, 1, G[EP_CONV1], b.dT3, st));
+    }
+    // ---- input T-Net ----------------------------------------------------------------------------------------------
+    TRY(e.tnet_fc_bwd(EP_IT, BN_T1, b.dT3, 9, f.pool_t, f.z_tf1, f.z_tf2));
+    TRY(e.pool(b.d_pool, 1, f.arg_t, f.z_t3, BN_T3));
+    {
+        const GradSrc g = e.sparse(f.arg_t, b.dpm, 1, f.z_t3, BN_T3);
+        TRY(e.wgrad(g, e.act(f.z_t2, BN_T2, 128), G[EP_IT + TP_CONV3]));
+        TRY(e.dgrad(g, P[EP_IT + TP_CONV3], 128, f.z_t2, BN_T2, 128, nullptr, b.dyA));
+    }
+    {
+        const GradSrc g = e.dense(b.dyA, f.z_t2, BN_T2, 128);
+        TRY(e.wgrad(g, e.act(f.z_t1, BN_T1, 64), G[EP_IT + TP_CONV2]));
+        TRY(e.dgrad(g, P[EP_IT + TP_CONV2], 64, f.z_t1, BN_T1, 64, nullptr, b.dyB));
+    }
+    {
+        PwInputWgrad w;
+        w.x = x; w.dy = b.dyB; w.z = f.z_t1;
+        w.P1 = b.bn[BN_T1].P1; w.P2 = b.bn[BN_T1].P2; w.P3 = b.bn[BN_T1].P3;
+        w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
+        TRY(pw_input_wgrad(w, st));
+        TRY(input_param_grads(b.dWeff, P[EP_IT + TP_CONV1], nullptr, Q, n_slots, 0, 0, G[EP_IT + TP_CONV1], nullptr, st));
+    }
+    // ---- BatchNorm weight / bias gradients of the point layers (the FC BatchNorms wrote theirs directly) ----------
+    {
+        const int ids[12] = {BN_T1, BN_T2, BN_T3, BN_F1, BN_F2, BN_F3, BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};
+        const int gw[12] = {EP_IT + TP_BN1_W, EP_IT + TP_BN2_W, EP_IT + TP_BN3_W, EP_FT + TP_BN1_W, EP_FT + TP_BN2_W, EP_FT + TP_BN3_W,
+                            EP_BN1_W, EP_BN2_W, EP_BN3_W, EP_BN4_W, EP_BN5_W, EP_BN6_W};
+        BnGradItem items[12];
+        for (int i = 0; i < 12; ++i) items[i] = {b.bn[ids[i]].slot_ab, G[gw[i]], G[gw[i] + 1], f.bn[ids[i]].C, n_slots};
+        TRY(bn_param_grads(items, 12, st));
+    }
+    return AMPNET_OK;
+}

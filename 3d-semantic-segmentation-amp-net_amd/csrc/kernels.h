@@ -129,3 +129,111 @@ __host__ __device__ inline uint32_t drop_threshold(float p)
 }
 
 }  // namespace ampnet
+
+// =====================================================================================================
+// backward kernels (pw_bwd.hip, bwd_misc.hip)
+// =====================================================================================================
+namespace ampnet {
+
+// How the gradient wrt a layer's PRE-BatchNorm output z_l [rows, C] is produced on the fly:
+//   g = dy * P1[slot][c] + z * P2[slot][c] + P3[slot][c]          (BatchNorm backward folded into three constants)
+//   dy dense : dy[rows, C] = dL/d(bn output) already masked by ReLU/dropout
+//   dy sparse: dy[row][c] = (arg[q][c] == row) ? dpool[prow(q)][c] : 0   (backward of MaxPool1d)
+//   P1 == nullptr: g = dy (layers with no BatchNorm behind them)
+struct GradSrc {
+    const float *dy = nullptr;     // [rows, C] or nullptr (sparse)
+    const float *z = nullptr;      // [rows, C] (needed when P1 != nullptr)
+    const int *arg = nullptr;      // [Q, C]
+    const float *dpool = nullptr;  // [Q, C]
+    int dpool_slot_major = 0;
+    const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, C]
+    int C = 0;
+};
+
+// How the forward activation a_{l-1} [rows, C] is recomputed: relu(z * s + t) (+ dropout), or z itself
+struct ActSrc {
+    const float *z = nullptr;      // [rows, C]
+    const float *s = nullptr, *t = nullptr;   // [n_slots, C] or nullptr = identity
+    float drop_p = 0.f;
+    uint32_t drop_seed = 0;
+    int C = 0;
+};
+
+// data gradient: out[row, j] = sum_k g[row, k] * W[k, j]  (+ add[row, j]), then optionally the ReLU/dropout mask
+// of layer l-1 and the partial sums its BatchNorm backward needs
+struct PwDgrad {
+    GradSrc g;                     // K = g.C in {64, 128, 256}
+    const float *W = nullptr;      // shared torch weight [K = cout_l][ldw] (row k, column j); per window: see below
+    int ldw = 0;
+    long w_win_stride = 0;         // != 0: per-window matrix T[pidx][j][k] (the bmm transform), rows j, k contiguous
+    int perwin_slot_major = 0;
+    const float *add = nullptr;    // [rows, cp] or nullptr
+    ActSrc prev;                   // prev.z == nullptr: raw output, no mask, no partial sums
+    const float *prev_mean = nullptr, *prev_invstd = nullptr;   // [n_slots, cp]
+    float *out = nullptr;          // [rows, cp]
+    int cp = 0;                    // output columns (<= 128 per launch block, any multiple of 32 up to 256)
+    float *part_a = nullptr, *part_b = nullptr;   // [Q * chunks, cp]: sum dy, sum dy * zhat of layer l-1
+    const int *win_off = nullptr;
+    int Q = 0, n_slots = 1, chunk_rows = 512, chunks = 1;
+    long rows_hint = 0;
+};
+int pw_dgrad(const PwDgrad &a, hipStream_t st);
+
+// weight gradient per window: dWpart[q][cx][cy] = sum_rows X[row, cx] * Y[row, cy]; X = GradSrc, Y = ActSrc.
+// Optional dbpart[q][cx] = sum_rows X[row, cx].
+struct PwWgrad {
+    GradSrc x;
+    ActSrc y;
+    float *dWpart = nullptr;       // [Q][x.C][ldp] (ldp >= y.C)
+    int ldp = 0;
+    float *dbpart = nullptr;       // [Q][x.C] or nullptr
+    const int *win_off = nullptr;
+    int Q = 0, n_slots = 1;
+    long rows_hint = 0;
+};
+int pw_wgrad(const PwWgrad &a, hipStream_t st);
+
+// dst[i] (= or +=) sum_q part[q * stride + i], i < n, fixed order; dst row-remap for strided destinations:
+// element i = (r, c) with c < cols -> dst[r * ld_dst + c]
+int reduce_windows(const float *part, int Q, long stride, int rows, int cols, int ld_part, float *dst, int ld_dst, int accumulate,
+                   hipStream_t st);
+
+// BatchNorm backward constants of one layer from the partial sums of pw_dgrad / head_out_bwd / pool_bwd:
+//   per slot: A = sum dy, Bs = sum dy * zhat  ->  P1 = s, P2 = -s * invstd * Bs / n, P3 = -s * A / n - P2 * mean,
+//   slot_ab[slot][c] = (A, Bs) for the parameter gradients (dbeta = sum_slots A, dgamma = sum_slots Bs)
+struct BnBwdFinalize {
+    const float *part_a = nullptr, *part_b = nullptr;   // [Q * chunks, C]
+    const int *win_off = nullptr;                       // rows per slot are counted from it
+    int Q = 0, chunks = 1, n_slots = 1, C = 0;
+    const float *gamma = nullptr, *mean = nullptr, *invstd = nullptr;   // gamma [C]; mean / invstd [n_slots, C]
+    float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;  // [n_slots, C]
+    float *slot_ab = nullptr;                           // [n_slots, C, 2]
+};
+int bn_bwd_finalize(const BnBwdFinalize &a, hipStream_t st);
+
+struct BnGradItem {
+    const float *slot_ab;   // [n_slots, C, 2]
+    float *dgamma, *dbeta;  // [C]
+    int C, n_slots;
+};
+int bn_param_grads(const BnGradItem *items_host, int n, hipStream_t st);
+
+// MaxPool backward + the BatchNorm-backward constants of the pooled layer in one kernel
+struct PoolBwd {
+    const float *d_pooled = nullptr;   // [Q, C] grad wrt pooled (post-ReLU) activations, row = prow(q)
+    int slot_major = 0;
+    const int *arg = nullptr;          // [Q, C]
+    const float *z = nullptr;          // [rows, C] pre-BN output of the pooled layer
+    const float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;   // [n_slots, C]
+    const int *win_off = nullptr;
+    int Q = 0, n_slots = 1, C = 256;
+    float *dpm = nullptr;              // [Q, C] masked pooled grads, row = prow(q)
+    float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr, *slot_ab = nullptr;
+};
+int pool_bwd(const PoolBwd &a, hipStream_t st);
+
+// C[M, N] = op(A) * op(B) (+ C if accumulate); row-major, small problems (T-Net FC layers, attention projections)
+int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                int accumulate, hipStream_t st);
+
+}  // namespace ampnet

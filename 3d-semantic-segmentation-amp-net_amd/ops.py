@@ -147,3 +147,25 @@ def reg_loss(feat_T, keep_G=False):
         rc = _lib.lib().ampnet_reg_loss_fwd_f32(_lib.ptr(f), n, _lib.ptr(out), _lib.ptr(G), _lib.ptr(part), _lib.stream_ptr(dev))
     _lib.check(rc, "ampnet_reg_loss_fwd_f32")
     return (out, G) if keep_G else out
+
+
+def encoder_backward(enc_params, grad_table, x, win_off, n_windows, total_rows, max_rows, n_slots, local, feat_T,
+                     d_local, d_global, d_feat_T, fwd_ws, bwd_ws):
+    """Backward of a train-mode encoder_forward (same x / windows / n_slots; fwd_ws untouched since).
+    grad_table: PointerTable over the gradient tensors (same order as the parameters); gradients are overwritten."""
+    dev = x.device
+    L = _lib.lib()
+    L.ampnet_encoder_bwd_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_encoder_bwd_workspace_bytes(n_windows, n_slots, total_rows, max_rows)
+    buf = bwd_ws.get(need, dev)
+    fbuf = fwd_ws.buf
+    for t, name, shape in ((d_local, "d_local", (total_rows, 64)), (d_global, "d_global", (n_windows, 256)),
+                           (d_feat_T, "d_feat_T", (n_windows, 64, 64))):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+            raise _lib.AmpnetError(f"encoder_backward: {name} must be contiguous float32 GPU {shape}, got {tuple(t.shape)} {t.dtype}")
+    with torch.cuda.device(dev):
+        rc = L.ampnet_encoder_bwd_f32(enc_params.arr, grad_table.arr, _lib.ptr(x), _lib.ptr(win_off), n_windows, n_slots,
+                                      total_rows, max_rows, _lib.ptr(local), _lib.ptr(d_local), _lib.ptr(d_global),
+                                      _lib.ptr(d_feat_T), _lib.ptr(feat_T), _lib.ptr(fbuf), ctypes.c_size_t(fbuf.numel()),
+                                      _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_encoder_bwd_f32")

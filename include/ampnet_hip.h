@@ -97,6 +97,21 @@ int ampnet_encoder_fwd_f32(const float *const *params_host, float *const *buffer
                            float *local, float *global_feat, float *feat_T, float *in_T, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- a2/a3 backward -----------------------------------------------------------------------------------
+ * replaces autograd's backward through BasePointNet.forward (the reference: loss.backward(),
+ * train_pointnet-attention.py:467) for all windows of a step.  Must follow a train-mode
+ * ampnet_encoder_fwd_f32 on the same x / win_off / Q / n_slots with `fwd_workspace` untouched in between.
+ *   grads_host [52] device pointers, same order as params_host; every gradient is WRITTEN (not accumulated)
+ *   local, feat_T   the forward's outputs (read)
+ *   d_local  [total_rows, 64] or NULL; d_global [Q, 256] (row q); d_feat_T [Q, 64, 64] (slot-major rows, like
+ *            feat_T in train mode) or NULL: gradients of the loss wrt the three forward outputs.         */
+size_t ampnet_encoder_bwd_workspace_bytes(int Q, int n_slots, int total_rows, int max_rows);
+int ampnet_encoder_bwd_f32(const float *const *params_host, float *const *grads_host, const float *x,
+                           const int32_t *win_off, int Q, int n_slots, int total_rows, int max_rows,
+                           const float *local, const float *d_local, const float *d_global, const float *d_feat_T,
+                           const float *feat_T, void *fwd_workspace, size_t fwd_workspace_bytes, void *bwd_workspace,
+                           size_t bwd_workspace_bytes, void *stream);
+
 /* ---- a4 (+a6 forward): attention head -------------------------------------------------------------
  * replaces SegmentationWithAttention.forward (pointNet/model/pointnetAtt.py:176-209) and, optionally, the
  * loss / prediction lines of train_loop (train_pointnet-attention.py:138,445-450).
