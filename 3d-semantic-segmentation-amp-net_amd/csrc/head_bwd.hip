@@ -1,0 +1,378 @@
+// head_bwd.hip -- C ABI: ampnet_head_bwd_f32 = autograd backward of SegmentationWithAttention.forward
+// (pointNet/model/pointnetAtt.py:176-209) given dL/dlogits; returns dL/d(local features), dL/d(window tokens)
+// and writes every parameter gradient.  Reverse of head.hip's launch sequence:
+//   head_out_bwd (conv_4, dropout, bn_3 ReLU mask)  -> pw_wgrad/pw_dgrad conv_3 -> pw_wgrad/pw_dgrad conv_2
+//   (the per-window column sums of conv_2's gradient ARE the gradient of the per-window token bias)
+//   -> small SGEMMs for the token half of conv_2, out_proj, in_proj -> attention_core_bwd -> posenc backward.
+#include "bwd_misc.h"
+#include "head.h"
+
+namespace ampnet {
+namespace {
+
+constexpr int HB_ROWS = 128;
+
+struct HeadOutBwd {
+    const float *dlogits;      // [B, C, P]
+    const float *z3;           // [R, 64]
+    const float *scale, *shift, *mean, *invstd;   // bn_3 [64]
+    const float *W;            // [C, 64]
+    float drop_p;
+    uint32_t drop_seed;
+    int R, P, C;
+    float *dy3;                // [R, 64] masked gradient wrt bn_3 output
+    float *part_a, *part_b;    // [blocks, 64]
+    float *dWpart;             // [blocks, C * 64 + C]
+};
+
+__global__ __launch_bounds__(HB_ROWS) void head_out_bwd_kernel(HeadOutBwd a)
+{
+    __shared__ float sA[HB_ROWS][65];      // a3 = dropout(relu(bn_3(z3))), later dy3
+    __shared__ float sZ[HB_ROWS][65];      // zhat of z3
+    __shared__ float sD[HB_ROWS][HEAD_MAX_CLASSES];
+    __shared__ float sW[HEAD_MAX_CLASSES][64], sSc[64], sSh[64], sMe[64], sIs[64];
+    const int tid = threadIdx.x, row0 = blockIdx.x * HB_ROWS;
+    const int n = min(HB_ROWS, a.R - row0);
+    for (int e = tid; e < a.C * 64; e += HB_ROWS) sW[e / 64][e % 64] = a.W[e];
+    if (tid < 64) {
+        sSc[tid] = a.scale[tid];
+        sSh[tid] = a.shift[tid];
+        sMe[tid] = a.mean[tid];
+        sIs[tid] = a.invstd[tid];
+    }
+    __syncthreads();
+    const uint32_t thr = drop_threshold(a.drop_p);
+    const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    for (int e = tid; e < HB_ROWS * 64; e += HB_ROWS) {
+        const int i = e / 64, k = e % 64;
+        float av = 0.f, zh = 0.f;
+        if (i < n) {
+            const float zv = a.z3[(size_t)(row0 + i) * 64 + k];
+            zh = (zv - sMe[k]) * sIs[k];
+            av = fmaxf(fmaf(zv, sSc[k], sSh[k]), 0.f);
+            if (a.drop_p > 0.f) av = (mix32(((uint32_t)(row0 + i) * 64u + (uint32_t)k) ^ a.drop_seed) >= thr) ? av * dscale : 0.f;
+        }
+        sA[i][k] = av;
+        sZ[i][k] = zh;
+    }
+    {
+        const int row = row0 + tid;
+        for (int c = 0; c < HEAD_MAX_CLASSES; ++c) {
+            float d = 0.f;
+            if (tid < n && c < a.C) d = a.dlogits[((size_t)(row / a.P) * a.C + c) * a.P + row % a.P];
+            sD[tid][c] = d;
+        }
+    }
+    __syncthreads();
+    // conv_4 weight / bias gradient partial of this block: (c, k) pairs over the block's rows
+    for (int e = tid; e < a.C * 64 + a.C; e += HB_ROWS) {
+        float s = 0.f;
+        if (e < a.C * 64) {
+            const int c = e / 64, k = e % 64;
+            for (int i = 0; i < n; ++i) s = fmaf(sD[i][c], sA[i][k], s);
+        } else {
+            const int c = e - a.C * 64;
+            for (int i = 0; i < n; ++i) s += sD[i][c];
+        }
+        a.dWpart[(size_t)blockIdx.x * (a.C * 64 + a.C) + e] = s;
+    }
+    __syncthreads();
+    // da3 = dlogits . W, masked -> dy3 (overwrites sA row by row: each thread owns its row)
+    if (tid < n) {
+        const int row = row0 + tid;
+        for (int k = 0; k < 64; ++k) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < HEAD_MAX_CLASSES; ++c)
+                if (c < a.C) v = fmaf(sD[tid][c], sW[c][k], v);
+            const bool live = sA[tid][k] > 0.f;       // relu > 0 and kept by dropout
+            if (a.drop_p > 0.f) v *= dscale;
+            (void)row;
+            sA[tid][k] = live ? v : 0.f;
+        }
+    } else {
+        for (int k = 0; k < 64; ++k) sA[tid][k] = 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 64; e += HB_ROWS) a.dy3[(size_t)row0 * 64 + e] = sA[e / 64][e % 64];
+    if (tid < 64) {
+        float sa = 0.f, sb = 0.f;
+        for (int i = 0; i < n; ++i) {
+            sa += sA[i][tid];
+            sb = fmaf(sA[i][tid], sZ[i][tid], sb);
+        }
+        a.part_a[(size_t)blockIdx.x * 64 + tid] = sa;
+        a.part_b[(size_t)blockIdx.x * 64 + tid] = sb;
+    }
+}
+
+// per (sample, head): gradients of softmax(q k^T) [dropout] v  wrt q, k, v
+__global__ __launch_bounds__(64) void attention_core_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ probs,
+                                                               const float *__restrict__ dctx, float *__restrict__ dqkv, int W,
+                                                               float drop_p, uint32_t drop_base_)
+{
+    __shared__ float sq[HEAD_MAX_W][HEAD_D + 1], sk[HEAD_MAX_W][HEAD_D + 1], sv[HEAD_MAX_W][HEAD_D + 1], sdc[HEAD_MAX_W][HEAD_D + 1];
+    __shared__ float sp[HEAD_MAX_W][HEAD_MAX_W + 1], spd[HEAD_MAX_W][HEAD_MAX_W + 1], sds[HEAD_MAX_W][HEAD_MAX_W + 1];
+    const int b = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+    const float qscale = 0.17677669529663687f;
+    for (int e = lane; e < W * HEAD_D; e += 64) {
+        const int i = e / HEAD_D, d = e % HEAD_D;
+        const size_t o = (size_t)(b * W + i) * (3 * HEAD_E) + hd * HEAD_D + d;
+        sq[i][d] = qkv[o] * qscale;
+        sk[i][d] = qkv[o + HEAD_E];
+        sv[i][d] = qkv[o + 2 * HEAD_E];
+        sdc[i][d] = dctx[(size_t)(b * W + i) * HEAD_E + hd * HEAD_D + d];
+    }
+    const uint32_t thr = drop_threshold(drop_p);
+    const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (int e = lane; e < W * W; e += 64) {
+        const int i = e / W, j = e % W;
+        const size_t o = ((size_t)(b * HEAD_HEADS + hd) * W + i) * W + j;
+        const float p = probs[o];
+        float keep = dscale;
+        if (drop_p > 0.f) keep = (mix32((uint32_t)o ^ drop_base_) >= thr) ? dscale : 0.f;
+        sp[i][j] = p;
+        spd[i][j] = p * keep;          // dropped probabilities (what multiplied v in the forward)
+        sds[i][j] = keep;              // keep factor, reused below
+    }
+    __syncthreads();
+    // dv[j][d] = sum_i pd[i][j] dctx[i][d]
+    for (int e = lane; e < W * HEAD_D; e += 64) {
+        const int j = e / HEAD_D, d = e % HEAD_D;
+        float acc = 0.f;
+        for (int i = 0; i < W; ++i) acc = fmaf(spd[i][j], sdc[i][d], acc);
+        dqkv[(size_t)(b * W + j) * (3 * HEAD_E) + 2 * HEAD_E + hd * HEAD_D + d] = acc;
+    }
+    // dP[i][j] = keep * sum_d dctx[i][d] v[j][d]
+    for (int e = lane; e < W * W; e += 64) {
+        const int i = e / W, j = e % W;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HEAD_D; ++d) acc = fmaf(sdc[i][d], sv[j][d], acc);
+        spd[i][j] = acc * sds[i][j];
+    }
+    __syncthreads();
+    // dS = P * (dP - rowsum(dP * P))
+    if (lane < W) {
+        const int i = lane;
+        float dot = 0.f;
+        for (int j = 0; j < W; ++j) dot = fmaf(spd[i][j], sp[i][j], dot);
+        for (int j = 0; j < W; ++j) sds[i][j] = sp[i][j] * (spd[i][j] - dot);
+    }
+    __syncthreads();
+    for (int e = lane; e < W * HEAD_D; e += 64) {
+        const int i = e / HEAD_D, d = e % HEAD_D;
+        float dq = 0.f, dk = 0.f;
+        for (int j = 0; j < W; ++j) {
+            dq = fmaf(sds[i][j], sk[j][d], dq);
+            dk = fmaf(sds[j][i], sq[j][d], dk);
+        }
+        const size_t o = (size_t)(b * W + i) * (3 * HEAD_E) + hd * HEAD_D + d;
+        dqkv[o] = dq * qscale;
+        dqkv[o + HEAD_E] = dk;
+    }
+}
+
+// positional encoding backward: hidden activations recomputed per token
+__global__ __launch_bounds__(64) void posenc_hidden_kernel(const float *__restrict__ cent, const float *__restrict__ w1,
+                                                          const float *__restrict__ b1, int Q, float *__restrict__ hid, float *__restrict__ slope)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= Q * 16) return;
+    const int q = i / 16, e = i % 16;
+    const float v = fmaf(cent[q * 2 + 1], w1[e * 2 + 1], fmaf(cent[q * 2 + 0], w1[e * 2 + 0], b1[e]));
+    hid[i] = v > 0.f ? v : 0.01f * v;
+    slope[i] = v > 0.f ? 1.0f : 0.01f;
+}
+
+__global__ void mul_inplace_kernel(float *__restrict__ x, const float *__restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= y[i];
+}
+
+struct HeadBwdWs {
+    float *dy3, *dy2;              // [R,64] [R,128]
+    float *wpart, *dbpart;         // [Q, 128*128], [Q, 128]
+    float *w4part;                 // [blocks, C*64 + C]
+    float *part_a, *part_b;        // [max(Q*chunks, blocks), 128]
+    float *P1[2], *P2[2], *P3[2], *slot_ab[2];   // bn2 (128), bn3 (64)
+    float *d_g2, *d_ctx, *d_qkv, *hid, *slope, *d_hid;
+    int *tot_off;                  // {0, R}
+    size_t bytes;
+};
+
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T>
+    T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
+{
+    Carver c{reinterpret_cast<char *>(base)};
+    const size_t Q = (size_t)s.Q, R = (size_t)s.R;
+    const size_t blocks = (size_t)cdiv(s.R, HB_ROWS);
+    w.dy3 = c.take<float>(R * 64);
+    w.dy2 = c.take<float>(R * 128);
+    w.wpart = c.take<float>(Q * 128 * 128);
+    w.dbpart = c.take<float>(Q * 128);
+    w.w4part = c.take<float>(blocks * (HEAD_MAX_CLASSES * 64 + HEAD_MAX_CLASSES));
+    const size_t np = (Q * (size_t)s.chunks > blocks ? Q * (size_t)s.chunks : blocks) * 128;
+    w.part_a = c.take<float>(np);
+    w.part_b = c.take<float>(np);
+    const int Cs[2] = {128, 64};
+    for (int i = 0; i < 2; ++i) {
+        w.P1[i] = c.take<float>(Cs[i]);
+        w.P2[i] = c.take<float>(Cs[i]);
+        w.P3[i] = c.take<float>(Cs[i]);
+        w.slot_ab[i] = c.take<float>(2 * Cs[i]);
+    }
+    w.d_g2 = c.take<float>(Q * 256);
+    w.d_ctx = c.take<float>(Q * 256);
+    w.d_qkv = c.take<float>(Q * 768);
+    w.hid = c.take<float>(Q * 16);
+    w.slope = c.take<float>(Q * 16);
+    w.d_hid = c.take<float>(Q * 16);
+    w.tot_off = c.take<int>(2);
+    w.bytes = align_up(c.off, 256);
+}
+
+}  // namespace
+}  // namespace ampnet
+
+using namespace ampnet;
+
+#define TRY(x)                            \
+    do {                                  \
+        int rc_ = (x);                    \
+        if (rc_ != AMPNET_OK) return rc_; \
+    } while (0)
+
+extern "C" size_t ampnet_head_bwd_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes)
+{
+    if (B < 1 || W < 1 || total_rows < 1 || max_rows < 1) return 0;
+    HeadBwdWs w;
+    head_bwd_carve(head_shape(B, W, total_rows, max_rows, n_classes, 1), nullptr, w);
+    return w.bytes;
+}
+
+extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const *grads_host, const float *lo,
+                                   const float *centroids, const int32_t *win_off, int B, int W, int total_rows, int max_rows,
+                                   int n_classes, float drop_p, uint32_t seed, const float *dlogits, float *d_lo, float *d_gl,
+                                   void *fwd_workspace, size_t fwd_workspace_bytes, void *bwd_workspace,
+                                   size_t bwd_workspace_bytes, void *stream)
+{
+    AMPNET_REQUIRE(params_host && grads_host && lo && centroids && win_off && dlogits && d_lo && d_gl && fwd_workspace && bwd_workspace,
+                   "ampnet_head_bwd_f32: null pointer");
+    AMPNET_REQUIRE(B >= 1 && W >= 1 && W <= HEAD_MAX_W && total_rows % B == 0, "ampnet_head_bwd_f32: bad sizes");
+    AMPNET_REQUIRE(n_classes >= 1 && n_classes <= HEAD_MAX_CLASSES, "ampnet_head_bwd_f32: n_classes=%d", n_classes);
+    hipStream_t st = (hipStream_t)stream;
+    const HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, 1);
+    HeadWs f;
+    head_carve(s, fwd_workspace, f);
+    HeadBwdWs b;
+    head_bwd_carve(s, bwd_workspace, b);
+    if (f.bytes > fwd_workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_head_bwd_f32: forward workspace %zu B < %zu B", fwd_workspace_bytes, f.bytes);
+    if (b.bytes > bwd_workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_head_bwd_f32: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.bytes);
+    const float *const *P = params_host;
+    float *const *G = grads_host;
+    const int Q = s.Q, R = total_rows, C = n_classes;
+    const int blocks = cdiv(R, HB_ROWS);
+
+    TRY(fill_i32_ramp(b.tot_off, 2, R, st));
+    // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
+    {
+        HeadOutBwd o;
+        o.dlogits = dlogits; o.z3 = f.z3;
+        o.scale = f.bn3.scale; o.shift = f.bn3.shift; o.mean = f.bn3.mean; o.invstd = f.bn3.invstd;
+        o.W = P[HP_CONV4_W]; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
+        o.R = R; o.P = R / B; o.C = C;
+        o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
+        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(HB_ROWS), 0, st, o);
+        TRY(check_launch("head_out_bwd_kernel"));
+        TRY(reduce_windows(b.w4part, blocks, C * 64 + C, 1, C * 64, C * 64, G[HP_CONV4_W], C * 64, 0, st));
+        TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, G[HP_CONV4_B], C, 0, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = b.tot_off; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
+        fz.gamma = P[HP_BN3_W]; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
+        fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
+        TRY(bn_bwd_finalize(fz, st));
+    }
+    // ---- conv_3: z3 = dropout(relu(bn_2(z2))) W3^T + b3 --------------------------------------------------
+    GradSrc g3;
+    g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1];
+    ActSrc a2;
+    a2.z = f.z2; a2.C = 128; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
+    {
+        PwWgrad w;
+        w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R;
+        TRY(pw_wgrad(w, st));
+        TRY(reduce_windows(b.wpart, Q, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
+        TRY(reduce_windows(b.dbpart, Q, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
+        PwDgrad d;
+        d.g = g3; d.W = P[HP_CONV3_W]; d.ldw = 128; d.prev = a2; d.prev_mean = f.bn2.mean; d.prev_invstd = f.bn2.invstd;
+        d.out = b.dy2; d.cp = 128; d.part_a = b.part_a; d.part_b = b.part_b;
+        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
+        TRY(pw_dgrad(d, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = s.chunks; fz.n_slots = 1; fz.C = 128;
+        fz.gamma = P[HP_BN2_W]; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
+        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
+        TRY(bn_bwd_finalize(fz, st));
+    }
+    // ---- conv_2: z2 = lo W2[:, :64]^T + (token W2[:, 64:]^T + b2)[window] ------------------------------------
+    GradSrc g2;
+    g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0];
+    {
+        ActSrc yl;
+        yl.z = lo; yl.C = 64;
+        PwWgrad w;
+        w.x = g2; w.y = yl; w.dWpart = b.wpart; w.ldp = 64; w.dbpart = b.dbpart;      // dbpart[q] = d(token bias of window q)
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R;
+        TRY(pw_wgrad(w, st));
+        TRY(reduce_windows(b.wpart, Q, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
+        TRY(reduce_windows(b.dbpart, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
+        PwDgrad d;
+        d.g = g2; d.W = P[HP_CONV2_W]; d.ldw = 320; d.out = d_lo; d.cp = 64;
+        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
+        TRY(pw_dgrad(d, st));
+    }
+    // ---- token path: gbias = g2tok W2[:, 64:]^T + b2 ; g2tok = ctx Wo^T + bo ; qkv = tok Wi^T + bi -------------
+    const float *d_gbias = b.dbpart;                                                        // [Q, 128]
+    TRY(sgemm_small(1, 0, 128, 256, Q, d_gbias, 128, f.g2, 256, G[HP_CONV2_W] + 64, 320, 0, st));
+    TRY(sgemm_small(0, 0, Q, 256, 128, d_gbias, 128, P[HP_CONV2_W] + 64, 320, b.d_g2, 256, 0, st));
+    TRY(sgemm_small(1, 0, 256, 256, Q, b.d_g2, 256, f.ctx, 256, G[HP_OUTPROJ_W], 256, 0, st));
+    TRY(colsum(b.d_g2, Q, 256, G[HP_OUTPROJ_B], st));
+    TRY(sgemm_small(0, 0, Q, 256, 256, b.d_g2, 256, P[HP_OUTPROJ_W], 256, b.d_ctx, 256, 0, st));
+    hipLaunchKernelGGL(attention_core_bwd_kernel, dim3(B, HEAD_HEADS), dim3(64), 0, st, f.qkv, f.probs, b.d_ctx, b.d_qkv, W, drop_p,
+                       drop_base(seed, 0));
+    TRY(check_launch("attention_core_bwd_kernel"));
+    TRY(sgemm_small(1, 0, 768, 256, Q, b.d_qkv, 768, f.tok, 256, G[HP_INPROJ_W], 256, 0, st));
+    TRY(colsum(b.d_qkv, Q, 768, G[HP_INPROJ_B], st));
+    TRY(sgemm_small(0, 0, Q, 256, 768, b.d_qkv, 768, P[HP_INPROJ_W], 256, d_gl, 256, 0, st));   // d_tok = d_gl = d_pos
+    // ---- positional encoding: pos = leaky(cent W1^T + b1) W2^T + b2 --------------------------------------------
+    hipLaunchKernelGGL(posenc_hidden_kernel, dim3(cdiv(Q * 16, 64)), dim3(64), 0, st, centroids, P[HP_FC1_W], P[HP_FC1_B], Q, b.hid, b.slope);
+    TRY(check_launch("posenc_hidden_kernel"));
+    TRY(sgemm_small(1, 0, 256, 16, Q, d_gl, 256, b.hid, 16, G[HP_FC2_W], 16, 0, st));
+    TRY(colsum(d_gl, Q, 256, G[HP_FC2_B], st));
+    TRY(sgemm_small(0, 0, Q, 16, 256, d_gl, 256, P[HP_FC2_W], 16, b.d_hid, 16, 0, st));
+    hipLaunchKernelGGL(mul_inplace_kernel, dim3(cdiv(Q * 16, 256)), dim3(256), 0, st, b.d_hid, b.slope, Q * 16);
+    TRY(check_launch("mul_inplace_kernel"));
+    TRY(sgemm_small(1, 0, 16, 2, Q, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, 0, st));
+    TRY(colsum(b.d_hid, Q, 16, G[HP_FC1_B], st));
+    // ---- BatchNorm weight / bias gradients ---------------------------------------------------------------------------
+    {
+        BnGradItem items[2] = {{b.slot_ab[0], G[HP_BN2_W], G[HP_BN2_B], 128, 1}, {b.slot_ab[1], G[HP_BN3_W], G[HP_BN3_B], 64, 1}};
+        TRY(bn_param_grads(items, 2, st));
+    }
+    return AMPNET_OK;
+}

@@ -169,3 +169,39 @@ def encoder_backward(enc_params, grad_table, x, win_off, n_windows, total_rows, 
                                       _lib.ptr(d_feat_T), _lib.ptr(feat_T), _lib.ptr(fbuf), ctypes.c_size_t(fbuf.numel()),
                                       _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
     _lib.check(rc, "ampnet_encoder_bwd_f32")
+
+
+def head_backward(head_params, grad_table, lo, centroids, win_off, B, W, total_rows, max_rows, n_classes, drop_p, seed,
+                  dlogits, fwd_ws, bwd_ws):
+    """Backward of a train-mode head_forward (same arguments, fwd_ws untouched since) -> (d_lo [rows, 64], d_gl [B*W, 256])."""
+    dev = lo.device
+    L = _lib.lib()
+    L.ampnet_head_bwd_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_head_bwd_workspace_bytes(B, W, total_rows, max_rows, n_classes)
+    buf = bwd_ws.get(need, dev)
+    fbuf = fwd_ws.buf
+    Pp = total_rows // B
+    if tuple(dlogits.shape) != (B, n_classes, Pp) or dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
+        raise _lib.AmpnetError(f"head_backward: dlogits must be contiguous float32 [B, C, P], got {tuple(dlogits.shape)}")
+    d_lo = torch.empty((total_rows, 64), dtype=torch.float32, device=dev)
+    d_gl = torch.empty((B * W, 256), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.ampnet_head_bwd_f32(head_params.arr, grad_table.arr, _lib.ptr(lo.contiguous()), _lib.ptr(centroids.contiguous()),
+                                   _lib.ptr(win_off), B, W, total_rows, max_rows, n_classes, ctypes.c_float(drop_p),
+                                   ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(dlogits), _lib.ptr(d_lo), _lib.ptr(d_gl),
+                                   _lib.ptr(fbuf), ctypes.c_size_t(fbuf.numel()), _lib.ptr(buf), ctypes.c_size_t(buf.numel()),
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_head_bwd_f32")
+    return d_lo, d_gl
+
+
+def ce_backward(logits, targets, class_w, loss2, grad_scale=1.0):
+    """dlogits = grad_scale * d(ce)/d(logits) for the weighted-mean CE returned by head_forward (loss2 = [ce, sum w])."""
+    B, C, Pp = logits.shape
+    d = torch.empty_like(logits)
+    dev = logits.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_ce_bwd_f32(_lib.ptr(logits), _lib.ptr(targets), _lib.ptr(class_w), _lib.ptr(loss2),
+                                          ctypes.c_float(grad_scale), B, C, Pp, _lib.ptr(d), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_ce_bwd_f32")
+    return d

@@ -135,6 +135,18 @@ int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_h
                         const float *class_w, long long *preds, float *loss_out, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* ---- a4 backward ---------------------------------------------------------------------------------------
+ * autograd backward of SegmentationWithAttention.forward given dlogits [B, n_classes, P].  Must follow a
+ * train-mode ampnet_head_fwd_f32 with the same arguments (drop_p, seed included) and an untouched fwd_workspace.
+ *   grads_host [18] device pointers in the order of the head parameters; every gradient is WRITTEN
+ *   d_lo [total_rows, 64] = dL/d(lo), d_gl [B * W, 256] = dL/d(gl) (row b * W + w); centroids get no gradient. */
+size_t ampnet_head_bwd_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes);
+int ampnet_head_bwd_f32(const float *const *params_host, float *const *grads_host, const float *lo,
+                        const float *centroids, const int32_t *win_off, int B, int W, int total_rows, int max_rows,
+                        int n_classes, float drop_p, uint32_t seed, const float *dlogits, float *d_lo, float *d_gl,
+                        void *fwd_workspace, size_t fwd_workspace_bytes, void *bwd_workspace,
+                        size_t bwd_workspace_bytes, void *stream);
+
 /* ---- a6: loss recipe (train_pointnet-attention.py:138,445,463-467) ------------------------------------
  * reg = || I - F F^T ||_F over the whole stack feat_T [n, 64, 64] (torch.norm of a 3-D tensor = Frobenius over
  * all elements).  G [n, 64, 64] (optional) receives I - F F^T for the backward; part [n] is scratch.

@@ -1,8 +1,12 @@
-"""GPU parity of the backward kernels (through the C ABI) with float64 autograd of the oracle.
+"""GPU parity of the backward kernels (through the C ABI) with autograd of the oracle.
 
-Tolerance: relative error of each gradient tensor in the L2 norm.  The T-Net FC BatchNorms normalise over only B
-rows, which makes fp32 gradients of the reference itself noisy (tests/test_oracle_golden.py: 2e-3 at B = 16), so
-the bar is 2e-2 for tensors behind those layers and 2e-3 elsewhere, plus a floor of 1e-5 of the global gradient norm."""
+The arbiter is the oracle evaluated in float64.  fp32 gradients of this network are ill-conditioned behind the
+T-Net FC BatchNorms (they normalise over only B rows): the reference's own fp32 gradients sit up to 2e-2 (relative
+L2) from a float64 evaluation of the same graph at B = 8 (tests/test_oracle_golden.py).  The bar for every
+gradient tensor therefore is: the HIP result is no further from float64 than FOUR times the distance of a float32
+torch-CPU evaluation of the same graph (two fp32 evaluations with different summation orders scatter by about that
+much around float64 on the input T-Net, the longest chain), plus 2e-3 of the tensor's norm and 1e-5 of the global
+gradient norm."""
 import os
 import sys
 
@@ -19,20 +23,21 @@ from helpers import torch_params                   # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _check_grads(got, want, loose, tight, what):
-    gtot = float(np.sqrt(sum(float(v.double().pow(2).sum()) for v in want.values())))
+def _check_grads(got, want64, want32, what):
+    gtot = float(np.sqrt(sum(float(v.double().pow(2).sum()) for v in want64.values())))
     bad = []
-    for k, w in want.items():
+    for k, w in want64.items():
         g = got[k].detach().cpu().double().reshape(w.shape)
         err = float((g - w).norm())
         ref = float(w.norm())
-        tol = (loose if ("transform" in k) else tight) * ref + 1e-5 * gtot
+        noise = float((want32[k].double() - w).norm())
+        tol = 4.0 * noise + 2e-3 * ref + 1e-5 * gtot
         if not err <= tol:
-            bad.append((k, err, ref))
-    assert not bad, f"{what}: " + "; ".join(f"{k}: err {e:.3e} vs |g| {r:.3e}" for k, e, r in bad[:8])
+            bad.append((k, err, noise, ref))
+    assert not bad, f"{what}: " + "; ".join(f"{k}: err {e:.3e} fp32-noise {n:.3e} |g| {r:.3e}" for k, e, n, r in bad[:8])
 
 
-@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160)])
+@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160), (64, 2, 64)])
 def test_encoder_backward_matches_oracle_autograd(synth, params, B, W, N):
     ops = sub("ops")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
@@ -52,18 +57,78 @@ def test_encoder_backward_matches_oracle_autograd(synth, params, B, W, N):
     r3 = synth.uniform(403, (Q, 64, 64), -1, 1)          # slot-major rows, like feat_T
     ops.encoder_backward(pt, gt, xd, off, Q, total, mx, W, local, ft, torch.from_numpy(r1).cuda(), torch.from_numpy(r2).cuda(),
                          torch.from_numpy(r3).cuda(), fws, bws)
-    # oracle: W encoder calls in float64, the same linear loss
-    op = {k: v.double().requires_grad_(True) for k, v in torch_params(synth.make_params(5, params.ENC_PARAMS)).items()}
-    ob = {k: v.double() for k, v in torch_params(synth.make_buffers(5, params.ENC_BUFFERS)).items()}
-    xw = torch.from_numpy(x).double().reshape(B, W, N, 9)
-    R1 = torch.from_numpy(r1).double().reshape(B, W, N, 64)
-    R2 = torch.from_numpy(r2).double().reshape(B, W, 256)
-    R3 = torch.from_numpy(r3).double().reshape(W, B, 64, 64)
-    loss = 0.0
-    for w in range(W):
-        l, g, t = O.encoder(op, ob, xw[:, w], train=True)
-        loss = loss + (l * R1[:, w]).sum() + (g * R2[:, w]).sum() + (t * R3[w]).sum()
-    loss.backward()
-    want = {k: v.grad for k, v in op.items()}
+    # oracle: W encoder calls, the same linear loss, in float64 (arbiter) and float32 (noise yardstick)
+    want = {}
+    for dt in (torch.float64, torch.float32):
+        op = {k: v.to(dt).requires_grad_(True) for k, v in torch_params(synth.make_params(5, params.ENC_PARAMS)).items()}
+        ob = {k: v.to(dt) for k, v in torch_params(synth.make_buffers(5, params.ENC_BUFFERS)).items()}
+        xw = torch.from_numpy(x).to(dt).reshape(B, W, N, 9)
+        R1 = torch.from_numpy(r1).to(dt).reshape(B, W, N, 64)
+        R2 = torch.from_numpy(r2).to(dt).reshape(B, W, 256)
+        R3 = torch.from_numpy(r3).to(dt).reshape(W, B, 64, 64)
+        loss = 0.0
+        for w in range(W):
+            l, g, t = O.encoder(op, ob, xw[:, w], train=True)
+            loss = loss + (l * R1[:, w]).sum() + (g * R2[:, w]).sum() + (t * R3[w]).sum()
+        loss.backward()
+        want[dt] = {k: v.grad for k, v in op.items()}
     assert all(torch.isfinite(g).all() for g in grads.values()), "a gradient was not written"
-    _check_grads(grads, want, 2e-2, 2e-3, "encoder")
+    _check_grads(grads, want[torch.float64], want[torch.float32], "encoder")
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.3])
+def test_head_backward_matches_oracle_autograd(synth, params, drop_p):
+    ops = sub("ops")
+    p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(7, params.HEAD_PARAMS).items()}
+    b = {k: torch.from_numpy(v).cuda() for k, v in synth.make_buffers(7, params.HEAD_BUFFERS).items()}
+    grads = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    pt = ops.PointerTable(params.HEAD_PARAMS, p, "p")
+    bt = ops.PointerTable(params.HEAD_BUFFERS, b, "b")
+    gt = ops.PointerTable(params.HEAD_PARAMS, grads, "g")
+    B, W, npc = 4, 3, [160, 96, 224]
+    Pp = sum(npc)
+    gl = synth.uniform(41, (W, B, 256), 0.0, 2.0)
+    lo = synth.uniform(42, (B, Pp, 64), -1.0, 1.0)
+    cent = synth.uniform(43, (B, W, 2), -1.0, 1.0)
+    tg = synth.randint(44, (B, Pp), -1, 5)
+    mask = torch.tensor([[False, True, False]] + [[False] * 3] * 3)
+    seed = 99
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0])
+    gld = torch.from_numpy(np.ascontiguousarray(gl.transpose(1, 0, 2)).reshape(B * W, 256)).cuda()
+    lod = torch.from_numpy(lo.reshape(-1, 64)).cuda()
+    centd = torch.from_numpy(cent).cuda()
+    off, total, mx = ops.window_offsets(npc * B, lod.device)
+    fws, bws = ops.Workspace(), ops.Workspace()
+    logits, _, loss = ops.head_forward(pt, bt, gld, lod, centd, off, mask, B, W, total, mx, 5, True, drop_p, seed, fws,
+                                       targets=torch.from_numpy(tg), class_w=cw)
+    dlog = ops.ce_backward(logits, torch.from_numpy(tg).cuda(), cw.cuda(), loss)
+    d_lo, d_gl = ops.head_backward(pt, gt, lod, centd, off, B, W, total, mx, 5, drop_p, seed, dlog, fws, bws)
+
+    def km(stream, n):
+        return O.keep_mask(seed, stream, n, drop_p)
+    want = {}
+    for dt in (torch.float64, torch.float32):
+        op = {k: v.to(dt).requires_grad_(True) for k, v in torch_params(synth.make_params(7, params.HEAD_PARAMS)).items()}
+        ob = {k: v.to(dt) for k, v in torch_params(synth.make_buffers(7, params.HEAD_BUFFERS)).items()}
+        masks = None
+        if drop_p > 0:
+            masks = {"att": torch.from_numpy(km(0, B * 8 * W * W)).to(dt).reshape(B * 8, W, W),
+                     "d2": torch.from_numpy(km(1, B * Pp * 128)).to(dt).reshape(B, Pp, 128).transpose(1, 2),
+                     "d3": torch.from_numpy(km(2, B * Pp * 64)).to(dt).reshape(B, Pp, 64).transpose(1, 2)}
+        glt = torch.from_numpy(gl).to(dt).requires_grad_(True)
+        lot = torch.from_numpy(lo).to(dt).requires_grad_(True)
+        lg = O.head(op, ob, glt, lot, torch.from_numpy(cent).to(dt), npc, mask, True, drop_p=drop_p, drop_masks=masks)
+        lsm = torch.log_softmax(lg.transpose(1, 2).reshape(-1, 5), dim=1)
+        t = torch.from_numpy(tg).reshape(-1)
+        keep = t >= 0
+        wi = cw.to(dt)[t.clamp(min=0)] * keep
+        ce = -(wi * lsm.gather(1, t.clamp(min=0)[:, None])[:, 0]).sum() / wi.sum()
+        ce.backward()
+        g = {k: v.grad for k, v in op.items()}
+        g["__d_lo"] = lot.grad.reshape(-1, 64)
+        g["__d_gl"] = glt.grad.transpose(0, 1).reshape(B * W, 256)
+        want[dt] = g
+    got = dict(grads)
+    got["__d_lo"], got["__d_gl"] = d_lo, d_gl
+    assert all(torch.isfinite(g).all() for g in got.values()), "a gradient was not written"
+    _check_grads(got, want[torch.float64], want[torch.float32], "head")
