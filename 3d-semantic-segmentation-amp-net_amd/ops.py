@@ -205,3 +205,15 @@ def ce_backward(logits, targets, class_w, loss2, grad_scale=1.0):
                                           ctypes.c_float(grad_scale), B, C, Pp, _lib.ptr(d), _lib.stream_ptr(dev))
     _lib.check(rc, "ampnet_ce_bwd_f32")
     return d
+
+
+def reg_loss_backward(feat_T, G, reg, coef, d_feat_T):
+    """d_feat_T += coef * d(reg)/d(feat_T); feat_T, G, d_feat_T [n, 64, 64] contiguous, reg [1]."""
+    n = feat_T.shape[0]
+    dev = feat_T.device
+    if not (feat_T.is_contiguous() and G.is_contiguous() and d_feat_T.is_contiguous()):
+        raise _lib.AmpnetError("reg_loss_backward: tensors must be contiguous")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_reg_loss_bwd_f32(_lib.ptr(feat_T), _lib.ptr(G), _lib.ptr(reg), ctypes.c_float(coef), n,
+                                                _lib.ptr(d_feat_T), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_reg_loss_bwd_f32")

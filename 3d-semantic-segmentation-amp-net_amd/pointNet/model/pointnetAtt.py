@@ -202,11 +202,15 @@ class SegmentationWithAttention(nn.Module):
         self._step = 0
         self.seed = 0x5EED
 
-    def _tables(self):
-        table = dict(P.HEAD_PARAMS)
+    def _param_table(self):
+        from collections import OrderedDict
+        table = OrderedDict(P.HEAD_PARAMS)
         table["conv_4.weight"] = (self.num_classes, 64, 1)
         table["conv_4.bias"] = (self.num_classes,)
-        return self._cache.get(self, table, P.HEAD_BUFFERS, "SegmentationWithAttention")
+        return table
+
+    def _tables(self):
+        return self._cache.get(self, self._param_table(), P.HEAD_BUFFERS, "SegmentationWithAttention")
 
     def forward_rows(self, gl_rows, lo_rows, centroids, np_cluster, attn_mask=None, targets=None, class_w=None,
                      want_preds=False):

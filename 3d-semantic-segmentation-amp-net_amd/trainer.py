@@ -1,0 +1,177 @@
+"""Fused AMP-Net training step on the HIP path and the optimiser that goes with it.
+
+fused_train_step() is what the package's train_loop runs in train mode: encoder forward (all B*W windows, per-slot
+BatchNorm statistics) -> head forward with fused weighted CE -> CE / reg-loss gradients -> head backward -> encoder
+backward -> gradient all-reduce when torch.distributed is initialised (RCCL, one flat bucket per network) ->
+optimizer.step() for the two optimisers the caller owns (FusedAdam below, or any torch optimiser: gradients are
+left in p.grad).  The reference does the same work with W serial encoder calls and autograd
+(train_pointnet-attention.py:396-470).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from . import params as P
+
+READY = True
+
+
+class GradStore:
+    """Flat float32 gradient buffer of a module with one 256-byte aligned view per parameter (p.grad = view), so the
+    backward kernels write straight into what the optimiser and the all-reduce read."""
+
+    def __init__(self, module, table):
+        named = dict(module.named_parameters())
+        self.names = list(table.keys())
+        dev = next(module.parameters()).device
+        offs, total = P.offsets({n: tuple(named[n].shape) for n in self.names})
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = {n: self.flat[o:o + k].view(named[n].shape) for n, (o, k) in offs.items()}
+        self.table = ops.PointerTable({n: tuple(named[n].shape) for n in self.names}, self.views, "gradients")
+        self.params = named
+
+    def attach(self):
+        for n in self.names:
+            self.params[n].grad = self.views[n]
+
+
+def _store(module, table):
+    st = getattr(module, "_grad_store", None)
+    if st is None or st.flat.device != next(module.parameters()).device:
+        st = GradStore(module, table)
+        module._grad_store = st
+    return st
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's interface and state_dict layout (step / exp_avg / exp_avg_sq per parameter) on the
+    multi-tensor HIP kernel ampnet_adam_step_f32.  No weight decay, no amsgrad (the reference uses neither)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise _lib.AmpnetError("FusedAdam: closures are not supported")
+        L = _lib.lib()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            steps = set()
+            for p in ps:
+                _lib.require_gpu(p, "parameter")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                steps.add(int(st["step"].item()))
+            if len(steps) != 1:
+                raise _lib.AmpnetError("FusedAdam: parameters of one group must share their step count")
+            n = len(ps)
+            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
+            numel = (ctypes.c_long * n)(*[p.numel() for p in ps])
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            dev = ps[0].device
+            b1, b2 = group["betas"]
+            with torch.cuda.device(dev):
+                rc = L.ampnet_adam_step_f32(arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
+                                            arr([self.state[p]["exp_avg_sq"] for p in ps]), numel, n,
+                                            ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
+                                            ctypes.c_float(group["eps"]), steps.pop(), ctypes.c_float(self.grad_scale),
+                                            _lib.stream_ptr(dev))
+            _lib.check(rc, "ampnet_adam_step_f32")
+        return None
+
+
+def _dist_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size()
+    return None, 1
+
+
+def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.001):
+    """Forward + loss + backward of one batch; gradients land in p.grad (views of the modules' flat buffers).
+    x [B, W, N, 9] f32, t [B, W, N] i64 (host or device), centroids [B, W, 2]."""
+    dev = next(pointnet.parameters()).device
+    if dev.type != "cuda":
+        raise _lib.AmpnetError("the AMP-Net HIP path needs the model on the GPU")
+    if not (pointnet.training and att_net.training):
+        raise _lib.AmpnetError("forward_backward needs both modules in train mode")
+    xd = torch.as_tensor(x).to(dev, non_blocking=True).float()
+    B, W, N, _ = xd.shape
+    targets_pc = torch.as_tensor(t).reshape(B, W * N)
+    tgd = targets_pc.to(dev, non_blocking=True)
+    cent = torch.as_tensor(centroids).to(dev).float().contiguous()
+    Q, rows = B * W, B * W * N
+    eg = _store(pointnet, P.ENC_PARAMS)
+    hg = _store(att_net, att_net._param_table())
+    ept, ebt = pointnet._tables()
+    hpt, hbt = att_net._tables()
+    xr = xd.reshape(rows, 9)
+    off, total, mx = ops.window_offsets([N] * Q, dev)
+    # ---- forward ----
+    local, glob, feat_T, _ = ops.encoder_forward(ept, ebt, xr, off, Q, total, mx, W, True, pointnet._ws)
+    pointnet._bump_batches(W)
+    mask = (tgd.view(B, -1, W) == -1).all(dim=1)                    # the reference's literal mask (amp_step.forward_batch)
+    seed = (att_net.seed + 0x632BE5AB * att_net._step) & 0xFFFFFFFF
+    att_net._step += 1
+    logits, preds, loss2 = ops.head_forward(hpt, hbt, glob, local, cent, off, mask, B, W, total, mx, att_net.num_classes, True,
+                                            att_net.p_drop, seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
+    att_net.bn_2.num_batches_tracked += 1
+    att_net.bn_3.num_batches_tracked += 1
+    feat_last = feat_T[-B:]
+    reg, G = ops.reg_loss(feat_last, keep_G=True)
+    # ---- backward ----
+    if not hasattr(att_net, "_bws"):
+        att_net._bws, pointnet._bws = ops.Workspace(), ops.Workspace()
+    dlog = ops.ce_backward(logits, tgd, class_w, loss2)
+    d_lo, d_gl = ops.head_backward(hpt, hg.table, local, cent, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
+                                   dlog, att_net._ws, att_net._bws)
+    d_ft = torch.zeros_like(feat_T)
+    ops.reg_loss_backward(feat_last, G, reg, reg_weight, d_ft[-B:])
+    ops.encoder_backward(ept, eg.table, xr, off, Q, total, mx, W, local, feat_T, d_lo, d_gl, d_ft, pointnet._ws, pointnet._bws)
+    eg.attach()
+    hg.attach()
+    return dict(logits=logits, preds=preds, ce=loss2, reg=reg, targets_pc=targets_pc, B=B, grad_bufs=(eg.flat, hg.flat))
+
+
+def fused_train_step(pointnet, att_net, optimizer_pointnet, optimizer_att, x, t, centroids, class_w):
+    out = forward_backward(pointnet, att_net, x, t, centroids, class_w)
+    dist, world = _dist_world()
+    if world > 1:
+        for flat in out["grad_bufs"]:                                # one bucket per network, SUM then scale in Adam
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for opt in (optimizer_pointnet, optimizer_att):
+            if isinstance(opt, FusedAdam):
+                opt.grad_scale = 1.0 / world
+            else:
+                for g in opt.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            p.grad.mul_(1.0 / world)
+    optimizer_pointnet.step()
+    optimizer_att.step()
+    return out
+
+
+class Trainer:
+    """Owns the two FusedAdam optimisers of the reference recipe and runs fused steps (bench.py, smoke())."""
+
+    def __init__(self, pointnet, att_net, lr=1e-3, class_w=None, world_size=1):
+        self.pointnet, self.att_net = pointnet, att_net
+        self.opt_p = FusedAdam(pointnet.parameters(), lr=lr)
+        self.opt_a = FusedAdam(att_net.parameters(), lr=lr)
+        dev = next(pointnet.parameters()).device
+        self.class_w = (class_w if class_w is not None else torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0])).to(dev)
+        pointnet.train()
+        att_net.train()
+
+    def step(self, x, t, centroids):
+        return fused_train_step(self.pointnet, self.att_net, self.opt_p, self.opt_a, x, t, centroids, self.class_w)

@@ -159,6 +159,15 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- a7: optimiser -----------------------------------------------------------------------------------------
+ * replaces torch.optim.Adam.step as the reference configures it (train_pointnet-attention.py:140-141,469-470):
+ * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad; `step` counts from 1.  One launch updates a list of
+ * tensors: four HOST arrays of DEVICE pointers (parameter, gradient, exp_avg, exp_avg_sq) and a host array of sizes.
+ * grad_scale multiplies the gradient on the fly (1 / world_size after a SUM all-reduce).                     */
+int ampnet_adam_step_f32(float *const *params_host, const float *const *grads_host, float *const *m_host,
+                         float *const *v_host, const long *numel_host, int n_tensors, float lr, float beta1,
+                         float beta2, float eps, int step, float grad_scale, void *stream);
+
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------------------------
  * ampnet_profile_enable(1) clears the table and brackets every instrumented kernel launch with two HIP events on
  * the launch stream; ampnet_profile_read() synchronises the device and sums elapsed ms, launches, algorithmic

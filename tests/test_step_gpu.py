@@ -81,3 +81,49 @@ def test_reference_signature_forward_eval(golden, synth, params):
     assert logits.shape == (2, 5, 768) and zero == 0
     with pytest.raises(Exception):
         enc(x.cpu())                                                 # no CPU fallback
+
+
+def test_train_loop_two_steps_match_reference(golden, synth, params):
+    """The reference's own train_loop ran two train steps on this seeded batch (dropout p = 0, make_golden.py:sec_step).
+    Step 1 pins loss terms and every gradient norm; both steps pin the Adam update (parameter |sum| after the step)."""
+    S = sub("pointNet.amp_step")
+    T = sub("trainer")
+    enc, att = _models(synth, params, dropout=0.0)
+    g, data = _batch(golden, synth)
+    W = int(g["meta"][2])
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
+    opt_p = T.FusedAdam(enc.parameters(), lr=1e-3)
+    opt_a = T.FusedAdam(att.parameters(), lr=1e-3)
+    for step in (1, 2):
+        np.random.seed(1000 + step)
+        d = (data[0].clone(), data[1].clone(), data[2], data[3])
+        m, tpc, preds, _ = S.train_loop(d, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+        rt = 1e-4 if step == 1 else 2e-3          # step 2 inherits Adam's sign-flip noise (test_oracle_golden.py)
+        for k in ("ce", "reg", "loss"):
+            want = g[f"s{step}_{k}"].item()
+            assert abs(m[k + "_loss" if k != "loss" else "loss"].item() - want) <= rt * abs(want), (step, k)
+        assert np.array_equal(tpc.numpy(), g[f"s{step}_targets"])
+        if step == 1:
+            assert (preds.numpy() != g["s1_preds"]).mean() < 2e-3
+            gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith("s1_") and "_gnorm/" in k))
+            for tag, mod in (("enc", enc), ("att", att)):
+                for k, p in mod.named_parameters():
+                    gn = g[f"s1_{tag}_gnorm/{k}"]
+                    got = p.grad.double()
+                    # the reference's fp32 gradients are themselves up to 2e-2 from float64 here (B = 16)
+                    assert abs(got.norm().item() - gn[0]) <= 3e-2 * gn[0] + 1e-5 * gtot, (k, got.norm().item(), gn[0])
+                    key = f"s1_{tag}_grad/{k}"
+                    if key in g.files:
+                        err = np.linalg.norm(got.cpu().numpy() - g[key].astype(np.float64))
+                        assert err <= 3e-2 * gn[0] + 1e-5 * gtot, (k, err, gn[0])
+        for tag, mod in (("enc", enc), ("att", att)):
+            for k, p in mod.named_parameters():
+                ps = g[f"s{step}_{tag}_psum/{k}"]
+                np.testing.assert_allclose(p.detach().double().abs().sum().item(), ps[1], rtol=2e-4,
+                                           atol=2.1e-3 * step * max(1.0, 0.02 * p.numel()), err_msg=k)
+    assert int(enc.bn_1.num_batches_tracked) == 2 * W and int(att.bn_2.num_batches_tracked) == 2
+    for tag, mod in (("enc", enc), ("att", att)):
+        sd = mod.state_dict()
+        for k in sd:
+            if "running" in k:
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"final_{tag}_buf/{k}"], rtol=1e-2, atol=2e-3, err_msg=k)
