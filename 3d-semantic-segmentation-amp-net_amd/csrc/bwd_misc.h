@@ -5,8 +5,8 @@
 namespace ampnet {
 
 int fc_act(const float *z, const float *s, const float *t, int rows, int C, int per, float *act, hipStream_t st);
-int fc_bn_bwd(const float *da, const float *z, const float *gamma, const float *scale, const float *shift, const float *mean,
-              const float *invstd, int n_slots, int per, int C, float *g, float *dgamma, float *dbeta, hipStream_t st);
+int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *shift, const float *mean, const float *invstd,
+              int n_slots, int per, int C, float *g, float *slot_ab, hipStream_t st);
 int colsum(const float *x, int rows, int C, float *out, hipStream_t st);
 int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st);
 

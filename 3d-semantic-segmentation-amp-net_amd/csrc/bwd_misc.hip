@@ -26,13 +26,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
     }
     ra[g][cl] = sa;
     rb[g][cl] = sb;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) rows_s = 0;
+    __syncthreads();
+    {
         int rows = 0;
-        for (int i = 0; i < per_slot; ++i) {
+        for (int i = threadIdx.x; i < per_slot; i += 256) {
             const int q = slot + i * a.n_slots;
             rows += a.win_off[q + 1] - a.win_off[q];
         }
-        rows_s = rows;
+        if (rows) atomicAdd(&rows_s, rows);       // integer, order-independent
     }
     __syncthreads();
     if (g == 0 && c < a.C) {
@@ -226,45 +228,39 @@ int fc_act(const float *z, const float *s, const float *t, int rows, int C, int 
     return check_launch("fc_act_kernel");
 }
 
-// da [rows, C] = grad wrt relu(bn(z)); per (slot, channel): full BatchNorm backward over the slot's `per` rows
-__global__ __launch_bounds__(64) void fc_bn_bwd_kernel(const float *__restrict__ da, const float *__restrict__ z, const float *__restrict__ gamma,
+// da [rows, C] = grad wrt relu(bn(z)); block = (slot, 64 channels): full BatchNorm backward over the slot's `per` rows
+__global__ __launch_bounds__(64) void fc_bn_bwd_kernel(const float *__restrict__ da, const float *__restrict__ z,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
-                                                      const float *__restrict__ mean, const float *__restrict__ invstd, int n_slots, int per,
-                                                      int C, float *__restrict__ g, float *__restrict__ dgamma, float *__restrict__ dbeta)
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd, int per, int C,
+                                                      float *__restrict__ g, float *__restrict__ slot_ab)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
     if (c >= C) return;
-    float dg = 0.f, db = 0.f;
-    for (int s = 0; s < n_slots; ++s) {
-        const size_t so = (size_t)s * C + c;
-        const float sc = scale[so], sh = shift[so], mu = mean[so], is = invstd[so];
-        double A = 0.0, Bs = 0.0;
-        for (int i = 0; i < per; ++i) {
-            const size_t o = (size_t)(s * per + i) * C + c;
-            const float zv = z[o];
-            const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
-            A += (double)dy;
-            Bs += (double)dy * (double)((zv - mu) * is);
-        }
-        const float an = (float)(A / per), bn = (float)(Bs / per);
-        for (int i = 0; i < per; ++i) {
-            const size_t o = (size_t)(s * per + i) * C + c;
-            const float zv = z[o];
-            const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
-            g[o] = sc * (dy - an - (zv - mu) * is * bn);
-        }
-        db += (float)A;
-        dg += (float)Bs;
+    const size_t so = (size_t)s * C + c;
+    const float sc = scale[so], sh = shift[so], mu = mean[so], is = invstd[so];
+    double A = 0.0, Bs = 0.0;
+    for (int i = 0; i < per; ++i) {
+        const size_t o = (size_t)(s * per + i) * C + c;
+        const float zv = z[o];
+        const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
+        A += (double)dy;
+        Bs += (double)dy * (double)((zv - mu) * is);
     }
-    dgamma[c] = dg;
-    dbeta[c] = db;
+    const float an = (float)(A / per), bn = (float)(Bs / per);
+    for (int i = 0; i < per; ++i) {
+        const size_t o = (size_t)(s * per + i) * C + c;
+        const float zv = z[o];
+        const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
+        g[o] = sc * (dy - an - (zv - mu) * is * bn);
+    }
+    slot_ab[so * 2 + 0] = (float)A;
+    slot_ab[so * 2 + 1] = (float)Bs;
 }
 
-int fc_bn_bwd(const float *da, const float *z, const float *gamma, const float *scale, const float *shift, const float *mean,
-              const float *invstd, int n_slots, int per, int C, float *g, float *dgamma, float *dbeta, hipStream_t st)
+int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *shift, const float *mean, const float *invstd,
+              int n_slots, int per, int C, float *g, float *slot_ab, hipStream_t st)
 {
-    hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, da, z, gamma, scale, shift, mean, invstd, n_slots, per, C, g,
-                       dgamma, dbeta);
+    hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(n_slots, cdiv(C, 64)), dim3(64), 0, st, da, z, scale, shift, mean, invstd, per, C, g, slot_ab);
     return check_launch("fc_bn_bwd_kernel");
 }
 

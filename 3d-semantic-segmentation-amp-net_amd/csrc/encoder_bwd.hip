@@ -40,6 +40,9 @@ struct Carver {
     }
 };
 
+constexpr int WG_CHUNK_ROWS = 1024;     // rows per pw_wgrad workgroup
+static int wg_chunks(const EncShape &s) { return cdiv(s.max_rows, WG_CHUNK_ROWS); }
+
 static const int kBnC2[BN_ENC_COUNT] = {64, 128, 256, 256, 128, 64, 64, 64, 128, 256, 256, 128, 64, 128, 128, 256};
 
 void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
@@ -50,8 +53,8 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.dyB = c.take<float>(R * 128);
     w.d_local = c.take<float>(R * 64);
     w.d_h = c.take<float>(R * 64);
-    w.wpart = c.take<float>(Q * 256 * 128);
-    w.dbpart = c.take<float>(Q * 256);
+    w.wpart = c.take<float>(Q * (size_t)wg_chunks(s) * 256 * 128);
+    w.dbpart = c.take<float>(Q * (size_t)wg_chunks(s) * 256);
     w.dpm = c.take<float>(Q * 256);
     w.a1 = c.take<float>(Q * 256);
     w.a2 = c.take<float>(Q * 128);
@@ -117,8 +120,9 @@ struct EncBwd {
         PwWgrad w;
         w.x = x; w.y = y; w.dWpart = b.wpart; w.ldp = y.C;
         w.win_off = win_off; w.Q = s.Q; w.n_slots = s.n_slots; w.rows_hint = s.R;
+        w.chunk_rows = WG_CHUNK_ROWS; w.chunks = wg_chunks(s);
         TRY(pw_wgrad(w, st));
-        return reduce_windows(b.wpart, s.Q, (long)x.C * y.C, x.C, y.C, y.C, dW, y.C, 0, st);
+        return reduce_windows(b.wpart, s.Q * w.chunks, (long)x.C * y.C, x.C, y.C, y.C, dW, y.C, 0, st);
     }
     // dy of layer `prev_bn` (masked) + its BatchNorm-backward partial sums, then that layer's constants
     int dgrad(const GradSrc &g, const float *W, int ldw, const float *prev_z, int prev_bn, int cp, const float *add, float *out) const
@@ -162,13 +166,13 @@ struct EncBwd {
         TRY(sgemm_small(1, 0, kk, 128, Q, g3, kk, b.a2, 128, G[pbase + TP_FC3_W], 128, 0, st));
         TRY(colsum(g3, Q, kk, G[pbase + TP_FC3_B], st));
         TRY(sgemm_small(0, 0, Q, 128, kk, g3, kk, P[pbase + TP_FC3_W], 128, b.da2, 128, 0, st));
-        TRY(fc_bn_bwd(b.da2, zf2, P[pbase + TP_BN5_W], f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per,
-                      128, b.g2, G[pbase + TP_BN5_W], G[pbase + TP_BN5_B], st));
+        TRY(fc_bn_bwd(b.da2, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per, 128, b.g2,
+                      b.bn[bn0 + 4].slot_ab, st));
         // fc_2
         TRY(sgemm_small(1, 0, 128, 256, Q, b.g2, 128, b.a1, 256, G[pbase + TP_FC2], 256, 0, st));
         TRY(sgemm_small(0, 0, Q, 256, 128, b.g2, 128, P[pbase + TP_FC2], 256, b.da1, 256, 0, st));
-        TRY(fc_bn_bwd(b.da1, zf1, P[pbase + TP_BN4_W], f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per,
-                      256, b.g1, G[pbase + TP_BN4_W], G[pbase + TP_BN4_B], st));
+        TRY(fc_bn_bwd(b.da1, zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per, 256, b.g1,
+                      b.bn[bn0 + 3].slot_ab, st));
         // fc_1 on the pooled features
         TRY(sgemm_small(1, 0, 256, 256, Q, b.g1, 256, pooled, 256, G[pbase + TP_FC1], 256, 0, st));
         TRY(sgemm_small(0, 0, Q, 256, 256, b.g1, 256, P[pbase + TP_FC1], 256, b.d_pool, 256, 0, st));
@@ -317,14 +321,18 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(pw_input_wgrad(w, st));
         TRY(input_param_grads(b.dWeff, P[EP_IT + TP_CONV1], nullptr, Q, n_slots, 0, 0, G[EP_IT + TP_CONV1], nullptr, st));
     }
-    // ---- BatchNorm weight / bias gradients of the point layers (the FC BatchNorms wrote theirs directly) ----------
+    // ---- BatchNorm weight / bias gradients: sums over the slots of (sum dy, sum dy * zhat) -----------------------------
     {
-        const int ids[12] = {BN_T1, BN_T2, BN_T3, BN_F1, BN_F2, BN_F3, BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};
-        const int gw[12] = {EP_IT + TP_BN1_W, EP_IT + TP_BN2_W, EP_IT + TP_BN3_W, EP_FT + TP_BN1_W, EP_FT + TP_BN2_W, EP_FT + TP_BN3_W,
-                            EP_BN1_W, EP_BN2_W, EP_BN3_W, EP_BN4_W, EP_BN5_W, EP_BN6_W};
-        BnGradItem items[12];
-        for (int i = 0; i < 12; ++i) items[i] = {b.bn[ids[i]].slot_ab, G[gw[i]], G[gw[i] + 1], f.bn[ids[i]].C, n_slots};
-        TRY(bn_param_grads(items, 12, st));
+        const int ids[16] = {BN_T1, BN_T2, BN_T3, BN_T4, BN_T5, BN_F1, BN_F2, BN_F3, BN_F4, BN_F5, BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};
+        BnGradItem items[16];
+        for (int i = 0; i < 16; ++i) {
+            const int id = ids[i];
+            const int gw = id <= BN_T5 ? EP_IT + TP_BN1_W + 2 * (id - BN_T1)
+                                       : (id >= BN_F1 && id <= BN_F5 ? EP_FT + TP_BN1_W + 2 * (id - BN_F1)
+                                                                     : (id <= BN_C2 ? EP_BN1_W + 2 * (id - BN_C1) : EP_BN3_W + 2 * (id - BN_C3)));
+            items[i] = {b.bn[id].slot_ab, G[gw], G[gw + 1], f.bn[id].C, n_slots};
+        }
+        TRY(bn_param_grads(items, 16, st));
     }
     return AMPNET_OK;
 }

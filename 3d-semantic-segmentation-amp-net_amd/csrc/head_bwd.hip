@@ -193,7 +193,7 @@ __global__ void mul_inplace_kernel(float *__restrict__ x, const float *__restric
 
 struct HeadBwdWs {
     float *dy3, *dy2;              // [R,64] [R,128]
-    float *wpart, *dbpart;         // [Q, 128*128], [Q, 128]
+    float *wpart, *dbpart, *dgb;   // [Q * wchunks, 128*128], [Q * wchunks, 128], [Q, 128] gradient of the per-window token bias
     float *w4part;                 // [blocks, C*64 + C]
     float *part_a, *part_b;        // [max(Q*chunks, blocks), 128]
     float *P1[2], *P2[2], *P3[2], *slot_ab[2];   // bn2 (128), bn3 (64)
@@ -222,8 +222,10 @@ void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
     const size_t blocks = (size_t)cdiv(s.R, HB_ROWS);
     w.dy3 = c.take<float>(R * 64);
     w.dy2 = c.take<float>(R * 128);
-    w.wpart = c.take<float>(Q * 128 * 128);
-    w.dbpart = c.take<float>(Q * 128);
+    const size_t wch = (size_t)cdiv(s.max_rows, 1024);
+    w.wpart = c.take<float>(Q * wch * 128 * 128);
+    w.dbpart = c.take<float>(Q * wch * 128);
+    w.dgb = c.take<float>(Q * 128);
     w.w4part = c.take<float>(blocks * (HEAD_MAX_CLASSES * 64 + HEAD_MAX_CLASSES));
     const size_t np = (Q * (size_t)s.chunks > blocks ? Q * (size_t)s.chunks : blocks) * 128;
     w.part_a = c.take<float>(np);
@@ -286,6 +288,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     float *const *G = grads_host;
     const int Q = s.Q, R = total_rows, C = n_classes;
     const int blocks = cdiv(R, HB_ROWS);
+    const int wch = cdiv(max_rows, 1024);
 
     TRY(fill_i32_ramp(b.tot_off, 2, R, st));
     // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
@@ -314,10 +317,10 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     {
         PwWgrad w;
         w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
-        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R;
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
         TRY(pw_wgrad(w, st));
-        TRY(reduce_windows(b.wpart, Q, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
-        TRY(reduce_windows(b.dbpart, Q, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
+        TRY(reduce_windows(b.wpart, Q * wch, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
+        TRY(reduce_windows(b.dbpart, Q * wch, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
         PwDgrad d;
         d.g = g3; d.W = P[HP_CONV3_W]; d.ldw = 128; d.prev = a2; d.prev_mean = f.bn2.mean; d.prev_invstd = f.bn2.invstd;
         d.out = b.dy2; d.cp = 128; d.part_a = b.part_a; d.part_b = b.part_b;
@@ -337,17 +340,19 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
         yl.z = lo; yl.C = 64;
         PwWgrad w;
         w.x = g2; w.y = yl; w.dWpart = b.wpart; w.ldp = 64; w.dbpart = b.dbpart;      // dbpart[q] = d(token bias of window q)
-        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R;
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
         TRY(pw_wgrad(w, st));
-        TRY(reduce_windows(b.wpart, Q, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
-        TRY(reduce_windows(b.dbpart, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
+        TRY(reduce_windows(b.wpart, Q * wch, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
+        // per-window sums of the chunk partials = gradient of the per-window token bias; their sum = conv_2.bias gradient
+        TRY(reduce_windows(b.dbpart, wch, 128, Q, 128, wch * 128, b.dgb, 128, 0, st));
+        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
         PwDgrad d;
         d.g = g2; d.W = P[HP_CONV2_W]; d.ldw = 320; d.out = d_lo; d.cp = 64;
         d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
         TRY(pw_dgrad(d, st));
     }
     // ---- token path: gbias = g2tok W2[:, 64:]^T + b2 ; g2tok = ctx Wo^T + bo ; qkv = tok Wi^T + bi -------------
-    const float *d_gbias = b.dbpart;                                                        // [Q, 128]
+    const float *d_gbias = b.dgb;                                                           // [Q, 128]
     TRY(sgemm_small(1, 0, 128, 256, Q, d_gbias, 128, f.g2, 256, G[HP_CONV2_W] + 64, 320, 0, st));
     TRY(sgemm_small(0, 0, Q, 256, 128, d_gbias, 128, P[HP_CONV2_W] + 64, 320, b.d_g2, 256, 0, st));
     TRY(sgemm_small(1, 0, 256, 256, Q, b.d_g2, 256, f.ctx, 256, G[HP_OUTPROJ_W], 256, 0, st));

@@ -179,7 +179,7 @@ struct PwDgrad {
 };
 int pw_dgrad(const PwDgrad &a, hipStream_t st);
 
-// weight gradient per window: dWpart[q][cx][cy] = sum_rows X[row, cx] * Y[row, cy]; X = GradSrc, Y = ActSrc.
+// weight gradient per window chunk: dWpart[q * chunks + chunk][cx][cy] = sum_rows X[row, cx] * Y[row, cy]; X = GradSrc, Y = ActSrc.
 // Optional dbpart[q][cx] = sum_rows X[row, cx].
 struct PwWgrad {
     GradSrc x;
@@ -189,6 +189,7 @@ struct PwWgrad {
     float *dbpart = nullptr;       // [Q][x.C] or nullptr
     const int *win_off = nullptr;
     int Q = 0, n_slots = 1;
+    int chunk_rows = 1 << 30, chunks = 1;   // partial index = q * chunks + chunk; dWpart is [Q * chunks][x.C][ldp]
     long rows_hint = 0;
 };
 int pw_wgrad(const PwWgrad &a, hipStream_t st);

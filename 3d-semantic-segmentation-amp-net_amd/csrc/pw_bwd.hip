@@ -56,8 +56,10 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
     if (nrows > 0) {
         if (a.w_win_stride == 0) {
             // shared weight W[k][j] (torch [cout_l = K][cin_l]): transpose while staging
+            // consecutive lanes take consecutive k: the LDS writes are conflict-free, the 16-byte global reads are
+            // strided but L2-resident (the whole weight is <= 128 KB and every workgroup reads it)
             for (int e = tid; e < K * (CB / 4); e += BW_NW * 64) {
-                const int k = e / (CB / 4), j4 = e % (CB / 4);
+                const int k = e % K, j4 = e / K;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cb0 + 4 * j4 < a.cp) v = *reinterpret_cast<const f32x4 *>(a.W + (size_t)k * a.ldw + cb0 + 4 * j4);
 #pragma unroll
@@ -268,7 +270,8 @@ int pw_dgrad(const PwDgrad &a, hipStream_t st)
     AMPNET_REQUIRE(!a.g.P1 || (a.g.P2 && a.g.P3 && a.g.z), "pw_dgrad: BatchNorm constants incomplete");
     AMPNET_REQUIRE(a.cp >= 1 && a.cp % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_dgrad: cp / ldw must be multiples of 4");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.z), "pw_dgrad: partial sums need the previous layer");
-    const int nt = a.cp > 64 ? 4 : (a.cp > 32 ? 2 : 1);
+    int nt = a.cp > 64 ? 4 : (a.cp > 32 ? 2 : 1);
+    if (a.g.C == 256 && nt == 4) nt = 2;      // 128 x 260 floats of weights would leave one workgroup per CU
     switch (a.g.C) {
     case 64:
         return nt == 4 ? launch_dgrad<64, 4>(a, st) : (nt == 2 ? launch_dgrad<64, 2>(a, st) : launch_dgrad<64, 1>(a, st));
@@ -282,18 +285,29 @@ int pw_dgrad(const PwDgrad &a, hipStream_t st)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// pw_wgrad: one workgroup = one window x one 128 x 128 block of dW; loops 32-row blocks of the window
+// pw_wgrad: one workgroup = one chunk of one window x one (32*TX) x (32*TY) block of dW.  The block is split over
+// the 4 waves by TILES (never by rows), so every wave issues MFMAs whatever the layer shape:
+//   (TX,TY) = (2,2): 1 tile per wave    (4,2): wave w -> row-tile w, both column tiles    (2,4): transposed
+//   (4,4): 2 x 2 tiles per wave.
+// Operands are transformed once while staged into LDS (double buffered, one barrier per ROWS rows).
 // ----------------------------------------------------------------------------------------------------
-constexpr int WG_ROWS = 32;
-constexpr int WG_CB = 128;
-
+template <int TX, int TY, int ROWS>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
 {
-    __shared__ __attribute__((aligned(16))) float sX[2][WG_ROWS][WG_CB];
-    __shared__ __attribute__((aligned(16))) float sY[2][WG_ROWS][WG_CB];
+    constexpr int CXB = 32 * TX, CYB = 32 * TY;
+    constexpr int WX = (TX == 4 && TY == 2) ? 4 : ((TX == 2 && TY == 4) ? 1 : 2);
+    constexpr int WY = 4 / WX;
+    constexpr int TXW = TX / WX, TYW = TY / WY;
+    constexpr int QX = CXB / 4, QY = CYB / 4;            // float4 columns of a staged row
+    constexpr int SX = 256 / QX, SY = 256 / QY;          // rows covered per staging iteration
+    constexpr int NIX = ROWS / SX, NIY = ROWS / SY;
+    __shared__ __attribute__((aligned(16))) float sX[2][ROWS][CXB];
+    __shared__ __attribute__((aligned(16))) float sY[2][ROWS][CYB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int q = blockIdx.x, cx0 = blockIdx.y * WG_CB, cy0 = blockIdx.z * WG_CB;
-    const int row_begin = a.win_off[q], row_end = a.win_off[q + 1];
+    const int q = blockIdx.x / a.chunks, chunk = blockIdx.x % a.chunks;
+    const int cx0 = blockIdx.y * CXB, cy0 = blockIdx.z * CYB;
+    const int row_begin = a.win_off[q] + chunk * a.chunk_rows;
+    const int row_end = min(a.win_off[q + 1], row_begin + a.chunk_rows);
     const int slot = (a.n_slots > 1) ? (q % a.n_slots) : 0;
     const int CX = a.x.C, CY = a.y.C;
     const bool sparse = a.x.dy == nullptr;
@@ -303,9 +317,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
     const uint32_t dthr = drop_threshold(a.y.drop_p);
     const float dscale = y_drop ? 1.0f / (1.0f - a.y.drop_p) : 1.0f;
 
-    // staging role: column quad cq (4 channels), rows rs, rs + 8, rs + 16, rs + 24
-    const int cq = tid & 31, rs = tid >> 5;
-    const int xc = cx0 + 4 * cq, yc = cy0 + 4 * cq;
+    // staging roles
+    const int cqx = tid % QX, rsx = tid / QX, cqy = tid % QY, rsy = tid / QY;
+    const int xc = cx0 + 4 * cqx, yc = cy0 + 4 * cqy;
     const bool xok = xc < CX, yok = yc < CY;
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f}, ys = p1, yt = p2, dp = p2;
     i32x4 ar = {-1, -1, -1, -1};
@@ -326,28 +340,31 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
         yt = *reinterpret_cast<const f32x4 *>(a.y.t + (size_t)slot * CY + yc);
     }
 
-    f32x4 rx_dy[4], rx_z[4], ry_z[4];
+    f32x4 rx_dy[NIX], rx_z[NIX], ry_z[NIY];
     auto load_regs = [&](int blk_row0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = blk_row0 + rs + 8 * i;
-            const bool rok = row < row_end;
-            const size_t rr = (size_t)(rok ? row : row_begin);
+        for (int i = 0; i < NIX; ++i) {
+            const int row = blk_row0 + rsx + SX * i;
+            const size_t rr = (size_t)(row < row_end ? row : row_begin);
             if (xok) {
                 if (!sparse) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.x.dy + rr * CX + xc);
                 if (has_bn) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.x.z + rr * CX + xc);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int row = blk_row0 + rsy + SY * i;
+            const size_t rr = (size_t)(row < row_end ? row : row_begin);
             if (yok) ry_z[i] = *reinterpret_cast<const f32x4 *>(a.y.z + rr * CY + yc);
         }
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
     auto write_lds = [&](int buf, int blk_row0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = blk_row0 + rs + 8 * i;
-            const bool rok = row < row_end;
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
-            if (rok && xok) {
+        for (int i = 0; i < NIX; ++i) {
+            const int row = blk_row0 + rsx + SX * i;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (row < row_end && xok) {
                 f32x4 dyv;
                 if (sparse) {
 #pragma unroll
@@ -363,7 +380,13 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
                 }
                 dbacc += xv;
             }
-            if (rok && yok) {
+            *reinterpret_cast<f32x4 *>(&sX[buf][rsx + SX * i][4 * cqx]) = xv;
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int row = blk_row0 + rsy + SY * i;
+            f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+            if (row < row_end && yok) {
                 yv = ry_z[i];
                 if (y_act) {
 #pragma unroll
@@ -375,22 +398,20 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
                     }
                 }
             }
-            *reinterpret_cast<f32x4 *>(&sX[buf][rs + 8 * i][4 * cq]) = xv;
-            *reinterpret_cast<f32x4 *>(&sY[buf][rs + 8 * i][4 * cq]) = yv;
+            *reinterpret_cast<f32x4 *>(&sY[buf][rsy + SY * i][4 * cqy]) = yv;
         }
     };
 
-    // wave w owns dW tiles (cx tiles 2*(w>>1), +1) x (cy tiles 2*(w&1), +1)
-    const int tx0 = 2 * (wave >> 1), ty0 = 2 * (wave & 1);
-    f32x16 acc[2][2];
+    const int tx0 = (wave / WY) * TXW, ty0 = (wave % WY) * TYW;
+    f32x16 acc[TXW][TYW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TXW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TYW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nblk = (row_end - row_begin + WG_ROWS - 1) / WG_ROWS;
+    const int nblk = (max(row_end - row_begin, 0) + ROWS - 1) / ROWS;
     if (nblk > 0) {
         load_regs(row_begin);
         write_lds(0, row_begin);
@@ -399,43 +420,47 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
     for (int b = 0; b < nblk; ++b) {
         const int cur = b & 1;
         const bool more = b + 1 < nblk;
-        if (more) load_regs(row_begin + (b + 1) * WG_ROWS);
+        if (more) load_regs(row_begin + (b + 1) * ROWS);
 #pragma unroll 4
-        for (int s = 0; s < WG_ROWS / 2; ++s) {
-            const int kr = 2 * s + h;
-            const float xa0 = sX[cur][kr][32 * tx0 + r], xa1 = sX[cur][kr][32 * (tx0 + 1) + r];
-            const float yb0 = sY[cur][kr][32 * ty0 + r], yb1 = sY[cur][kr][32 * (ty0 + 1) + r];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0, yb0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0, yb1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1, yb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1, yb1, acc[1][1], 0, 0, 0);
+        for (int s2 = 0; s2 < ROWS / 2; ++s2) {
+            const int kr = 2 * s2 + h;
+            float xa[TXW], yb[TYW];
+#pragma unroll
+            for (int i = 0; i < TXW; ++i) xa[i] = sX[cur][kr][32 * (tx0 + i) + r];
+#pragma unroll
+            for (int j = 0; j < TYW; ++j) yb[j] = sY[cur][kr][32 * (ty0 + j) + r];
+#pragma unroll
+            for (int i = 0; i < TXW; ++i)
+#pragma unroll
+                for (int j = 0; j < TYW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) write_lds(cur ^ 1, row_begin + (b + 1) * WG_ROWS);
+        if (more) write_lds(cur ^ 1, row_begin + (b + 1) * ROWS);
         __syncthreads();
     }
 
-    // ---- write the window's partial: accumulator row = cx (registers), column = cy (lane) ----
+    // ---- the chunk's partial: accumulator row = cx (registers), column = cy (lane) ----
+    const size_t pbase = (size_t)blockIdx.x * CX;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TXW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TYW; ++j) {
             const int cy = cy0 + 32 * (ty0 + j) + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int cx = cx0 + 32 * (tx0 + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (cx < CX && cy < CY) a.dWpart[((size_t)q * CX + cx) * a.ldp + cy] = acc[i][j][e];
+                if (cx < CX && cy < CY) a.dWpart[(pbase + cx) * a.ldp + cy] = acc[i][j][e];
             }
         }
     if (a.dbpart && blockIdx.z == 0) {
-        float *red = &sX[0][0][0];        // [8][128]
+        float *red = &sX[0][0][0];        // [SX][CXB]
         __syncthreads();
-        *reinterpret_cast<f32x4 *>(red + rs * WG_CB + 4 * cq) = dbacc;
+        *reinterpret_cast<f32x4 *>(red + rsx * CXB + 4 * cqx) = dbacc;
         __syncthreads();
-        if (tid < WG_CB && cx0 + tid < CX) {
+        if (tid < CXB && cx0 + tid < CX) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) s += red[g * WG_CB + tid];
-            a.dbpart[(size_t)q * CX + cx0 + tid] = s;
+            for (int g = 0; g < SX; ++g) s += red[g * CXB + tid];
+            a.dbpart[pbase + cx0 + tid] = s;
         }
     }
 }
@@ -446,42 +471,58 @@ int pw_wgrad(const PwWgrad &a, hipStream_t st)
     AMPNET_REQUIRE(a.x.dy || (a.x.arg && a.x.dpool), "pw_wgrad: neither dense nor sparse gradient source");
     AMPNET_REQUIRE(!a.x.P1 || (a.x.P2 && a.x.P3 && a.x.z), "pw_wgrad: BatchNorm constants incomplete");
     AMPNET_REQUIRE(a.x.C % 4 == 0 && a.y.C % 4 == 0 && a.ldp >= a.y.C, "pw_wgrad: channel counts must be multiples of 4");
+    AMPNET_REQUIRE(a.chunks >= 1 && a.chunk_rows % 64 == 0, "pw_wgrad: chunk_rows must be a multiple of 64");
     char name[64];
     snprintf(name, sizeof(name), "pw_wgrad<%d,%d>%s", a.x.C, a.y.C, a.x.dy ? "" : "+sparse");
     const double rows = (double)a.rows_hint;
+    const int tx = a.x.C > 64 ? 4 : 2, ty = a.y.C > 64 ? 4 : 2;
     ProfScope prof(name, 2.0 * rows * a.x.C * a.y.C,
-                   rows * 4.0 * (((a.x.dy ? 1 : 0) + (a.x.P1 ? 1 : 0)) * (double)a.x.C * cdiv(a.y.C, WG_CB) + (double)a.y.C * cdiv(a.x.C, WG_CB)), st);
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.Q, cdiv(a.x.C, WG_CB), cdiv(a.y.C, WG_CB)), dim3(256), 0, st, a);
+                   rows * 4.0 * (((a.x.dy ? 1 : 0) + (a.x.P1 ? 1 : 0)) * (double)a.x.C * cdiv(a.y.C, 32 * ty) + (double)a.y.C * cdiv(a.x.C, 32 * tx)), st);
+    dim3 grid(a.Q * a.chunks, cdiv(a.x.C, 32 * tx), cdiv(a.y.C, 32 * ty));
+    if (tx == 2 && ty == 2) hipLaunchKernelGGL((pw_wgrad_kernel<2, 2, 64>), grid, dim3(256), 0, st, a);
+    else if (tx == 4 && ty == 2) hipLaunchKernelGGL((pw_wgrad_kernel<4, 2, 32>), grid, dim3(256), 0, st, a);
+    else if (tx == 2 && ty == 4) hipLaunchKernelGGL((pw_wgrad_kernel<2, 4, 32>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pw_wgrad_kernel<4, 4, 32>), grid, dim3(256), 0, st, a);
     return check_launch("pw_wgrad_kernel");
 }
 
 // ----------------------------------------------------------------------------------------------------
+// reduce_windows: dst[r][c] (=|+=) sum_q part[q][r][c]; block = 32 elements x 8 partial groups, fixed order
+// ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_windows_kernel(const float *__restrict__ part, int Q, long stride, int rows, int cols,
                                                             int ld_part, float *__restrict__ dst, int ld_dst, int accumulate)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int rr = i / cols, c = i % cols;
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + el;
+    const bool ok = i < rows * cols;
+    const int rr = ok ? i / cols : 0, c = ok ? i % cols : 0;
     const float *p = part + (size_t)rr * ld_part + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int qi = 0;
-    for (; qi + 3 < Q; qi += 4) {
-        s0 += p[(size_t)qi * stride];
-        s1 += p[(size_t)(qi + 1) * stride];
-        s2 += p[(size_t)(qi + 2) * stride];
-        s3 += p[(size_t)(qi + 3) * stride];
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+        int qi = g;
+        for (; qi + 8 < Q; qi += 16) {
+            s0 += p[(size_t)qi * stride];
+            s1 += p[(size_t)(qi + 8) * stride];
+        }
+        if (qi < Q) s0 += p[(size_t)qi * stride];
     }
-    for (; qi < Q; ++qi) s0 += p[(size_t)qi * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    float *d = dst + (size_t)rr * ld_dst + c;
-    *d = accumulate ? *d + s : s;
+    red[g][el] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][el];
+        float *d = dst + (size_t)rr * ld_dst + c;
+        *d = accumulate ? *d + s : s;
+    }
 }
 
 int reduce_windows(const float *part, int Q, long stride, int rows, int cols, int ld_part, float *dst, int ld_dst, int accumulate,
                    hipStream_t st)
 {
     AMPNET_REQUIRE(part && dst && Q >= 1 && rows >= 1 && cols >= 1, "reduce_windows: bad arguments");
-    hipLaunchKernelGGL(reduce_windows_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, st, part, Q, stride, rows, cols, ld_part, dst,
+    hipLaunchKernelGGL(reduce_windows_kernel, dim3(cdiv(rows * cols, 32)), dim3(256), 0, st, part, Q, stride, rows, cols, ld_part, dst,
                        ld_dst, accumulate);
     return check_launch("reduce_windows_kernel");
 }

@@ -99,45 +99,47 @@ int pw_input(const PwInput &a, hipStream_t st)
 
 // ----------------------------------------------------------------------------------------------------
 // bn_finalize: block = (slot, 64 channels) x 4 groups; merges the per-chunk (mean, M2) partials of the slot's
-// windows with Chan's formula in double, in a fixed order: bitwise reproducible run to run.
+// windows in double, in a fixed order: bitwise reproducible run to run.
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
 {
-    __shared__ double rn[4][64], rmean[4][64], rm2[4][64];
+    // two passes over the slot's chunk partials (n_i, mean_i, M2_i), no division inside the loops:
+    //   mean = sum n_i mean_i / N;   M2 = sum (M2_i + n_i (mean_i - mean)^2)
+    __shared__ double rn[4][64], rs[4][64];
     const int slot = blockIdx.x;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;     // windows q = slot, slot + n_slots, ...
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    if (c < a.C) {
-        const int total = per_slot * a.chunks;
-        for (int e = g; e < total; e += 4) {
-            const int q = slot + (e / a.chunks) * a.n_slots;
-            const int ch = e % a.chunks;
-            const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
-            if (rows <= 0) continue;
-            const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
-            const double nw = (double)rows, mw = (double)a.part_sum[o], m2w = (double)a.part_sq[o];
-            const double nn = n + nw, delta = mw - mean;
-            mean += delta * nw / nn;
-            m2 += m2w + delta * delta * n * nw / nn;
-            n = nn;
-        }
+    const int total = per_slot * a.chunks;
+    const bool ok = c < a.C;
+    double n = 0.0, sm = 0.0;
+    for (int e = g; e < total; e += 4) {
+        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
+        const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
+        if (rows <= 0 || !ok) continue;
+        n += (double)rows;
+        sm += (double)rows * (double)a.part_sum[(size_t)(q * a.chunks + ch) * a.C + c];
     }
     rn[g][cl] = n;
-    rmean[g][cl] = mean;
-    rm2[g][cl] = m2;
+    rs[g][cl] = sm;
     __syncthreads();
-    if (g == 0 && c < a.C) {
-        for (int k = 1; k < 4; ++k) {
-            const double nw = rn[k][cl];
-            if (nw <= 0.0) continue;
-            const double nn = n + nw, delta = rmean[k][cl] - mean;
-            mean += delta * nw / nn;
-            m2 += rm2[k][cl] + delta * delta * n * nw / nn;
-            n = nn;
-        }
-        const double var = n > 0.0 ? m2 / n : 0.0;
+    const double N = (rn[0][cl] + rn[1][cl]) + (rn[2][cl] + rn[3][cl]);
+    const double mean = N > 0.0 ? ((rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl])) / N : 0.0;
+    __syncthreads();
+    double m2 = 0.0;
+    for (int e = g; e < total; e += 4) {
+        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
+        const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
+        if (rows <= 0 || !ok) continue;
+        const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
+        const double d = (double)a.part_sum[o] - mean;
+        m2 += (double)a.part_sq[o] + (double)rows * d * d;
+    }
+    rs[g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && ok) {
+        m2 = (rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl]);
+        const double var = N > 0.0 ? m2 / N : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
         const float sc = a.gamma[c] * invstd;
         const size_t o = (size_t)slot * a.C + c;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
         if (a.invstd) a.invstd[o] = invstd;
         if (a.stat_mean) {
             a.stat_mean[o] = (float)mean;
-            a.stat_uvar[o] = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
+            a.stat_uvar[o] = (float)(N > 1.0 ? m2 / (N - 1.0) : m2);
         }
     }
 }
