@@ -7,9 +7,11 @@ namespace ampnet {
 // ----------------------------------------------------------------------------------------------------
 // bn_bwd_finalize: block = (slot, 64 channels) x 4 groups over the slot's partials, fixed order
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
+constexpr int BFIN_G = 16;
+
+__global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinalize a)
 {
-    __shared__ double ra[4][64], rb[4][64];
+    __shared__ double ra[BFIN_G][64], rb[BFIN_G][64];
     __shared__ int rows_s;
     const int slot = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
     double sa = 0.0, sb = 0.0;
     if (c < a.C) {
         const int total = per_slot * a.chunks;
-        for (int e = g; e < total; e += 4) {
+        for (int e = g; e < total; e += BFIN_G) {
             const int q = slot + (e / a.chunks) * a.n_slots;
             const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
             sa += (double)a.part_a[o];
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
     __syncthreads();
     {
         int rows = 0;
-        for (int i = threadIdx.x; i < per_slot; i += 256) {
+        for (int i = threadIdx.x; i < per_slot; i += 64 * BFIN_G) {
             const int q = slot + i * a.n_slots;
             rows += a.win_off[q + 1] - a.win_off[q];
         }
@@ -38,8 +40,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
     }
     __syncthreads();
     if (g == 0 && c < a.C) {
-        const double A = (ra[0][cl] + ra[1][cl]) + (ra[2][cl] + ra[3][cl]);
-        const double Bs = (rb[0][cl] + rb[1][cl]) + (rb[2][cl] + rb[3][cl]);
+        double A = 0.0, Bs = 0.0;
+#pragma unroll
+        for (int k = 0; k < BFIN_G; ++k) {
+            A += ra[k][cl];
+            Bs += rb[k][cl];
+        }
         const double n = (double)rows_s;
         const size_t o = (size_t)slot * a.C + c;
         const double invstd = a.invstd[o], mean = a.mean[o];
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinalize a)
 int bn_bwd_finalize(const BnBwdFinalize &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.part_a && a.part_b && a.win_off && a.gamma && a.mean && a.invstd && a.P1 && a.P2 && a.P3 && a.slot_ab, "bn_bwd_finalize: null pointer");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * BFIN_G), 0, st, a);
     return check_launch("bn_bwd_finalize_kernel");
 }
 
@@ -137,53 +143,61 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// sgemm_small: 64 x 64 tile, 16-deep LDS slices, 4 x 4 outputs per thread (VALU fp32).
+// sgemm_small: 32 x 32 output tile, 32-deep LDS slices, 2 x 2 outputs per thread (VALU fp32); the next slice is
+// fetched into registers while the current one is multiplied.  The problems are tiny (M or N = a few hundred
+// rows): small tiles keep every CU busy, which matters more than per-block efficiency.
 // ----------------------------------------------------------------------------------------------------
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_small_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int accumulate)
 {
-    __shared__ float sA[16][65], sB[16][65];
+    __shared__ float sA[32][33], sB[32][33];     // [k][m], [k][n]
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int e = tid; e < 64 * 16; e += 256) {
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {};
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
             int m, k;
-            if (TA) { m = e % 64; k = e / 64; } else { k = e % 16; m = e / 16; }
+            if (TA) { m = e % 32; k = e / 32; } else { k = e % 32; m = e / 32; }
             const int gm = m0 + m, gk = k0 + k;
-            float v = 0.f;
-            if (gm < M && gk < K) v = TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-            sA[k][m] = v;
+            ra[i] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
+            int n, k2;
+            if (TB) { k2 = e % 32; n = e / 32; } else { n = e % 32; k2 = e / 32; }
+            const int gn = n0 + n, gk2 = k0 + k2;
+            rb[i] = (gn < N && gk2 < K) ? (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn]) : 0.f;
         }
-        for (int e = tid; e < 64 * 16; e += 256) {
-            int n, k;
-            if (TB) { k = e % 16; n = e / 16; } else { n = e % 64; k = e / 64; }
-            const int gn = n0 + n, gk = k0 + k;
-            float v = 0.f;
-            if (gn < N && gk < K) v = TB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
-            sB[k][n] = v;
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            if (TA) sA[e / 32][e % 32] = ra[i]; else sA[e % 32][e / 32] = ra[i];
+            if (TB) sB[e % 32][e / 32] = rb[i]; else sB[e / 32][e % 32] = rb[i];
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = sA[k][ty + 16 * i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = sB[k][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-        }
+        stash();
         __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = sA[k][ty], a1 = sA[k][ty + 16], b0 = sB[k][tx], b1 = sB[k][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]);
+            acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]);
+            acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int gm = m0 + ty + 16 * i;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int gn = n0 + tx + 16 * j;
             if (gm < M && gn < N) {
                 float *d = C + (size_t)gm * ldc + gn;
@@ -197,7 +211,7 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
                 int accumulate, hipStream_t st)
 {
     AMPNET_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1, "sgemm_small: bad arguments");
-    dim3 grid(cdiv(N, 64), cdiv(M, 64));
+    dim3 grid(cdiv(N, 32), cdiv(M, 32));
     char name[64];
     snprintf(name, sizeof(name), "sgemm_small");
     ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), st);

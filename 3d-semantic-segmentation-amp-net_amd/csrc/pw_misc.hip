@@ -101,11 +101,13 @@ int pw_input(const PwInput &a, hipStream_t st)
 // bn_finalize: block = (slot, 64 channels) x 4 groups; merges the per-chunk (mean, M2) partials of the slot's
 // windows in double, in a fixed order: bitwise reproducible run to run.
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
+constexpr int FIN_G = 16;      // partial groups per channel (block = 64 channels x 16 groups)
+
+__global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
 {
     // two passes over the slot's chunk partials (n_i, mean_i, M2_i), no division inside the loops:
     //   mean = sum n_i mean_i / N;   M2 = sum (M2_i + n_i (mean_i - mean)^2)
-    __shared__ double rn[4][64], rs[4][64];
+    __shared__ double rn[FIN_G][64], rs[FIN_G][64];
     const int slot = blockIdx.x;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
     const int total = per_slot * a.chunks;
     const bool ok = c < a.C;
     double n = 0.0, sm = 0.0;
-    for (int e = g; e < total; e += 4) {
+    for (int e = g; e < total; e += FIN_G) {
         const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
         const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
         if (rows <= 0 || !ok) continue;
@@ -123,11 +125,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
     rn[g][cl] = n;
     rs[g][cl] = sm;
     __syncthreads();
-    const double N = (rn[0][cl] + rn[1][cl]) + (rn[2][cl] + rn[3][cl]);
-    const double mean = N > 0.0 ? ((rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl])) / N : 0.0;
+    double N = 0.0, S = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_G; ++k) {
+        N += rn[k][cl];
+        S += rs[k][cl];
+    }
+    const double mean = N > 0.0 ? S / N : 0.0;
     __syncthreads();
     double m2 = 0.0;
-    for (int e = g; e < total; e += 4) {
+    for (int e = g; e < total; e += FIN_G) {
         const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
         const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
         if (rows <= 0 || !ok) continue;
@@ -138,7 +145,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
     rs[g][cl] = m2;
     __syncthreads();
     if (g == 0 && ok) {
-        m2 = (rs[0][cl] + rs[1][cl]) + (rs[2][cl] + rs[3][cl]);
+        m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < FIN_G; ++k) m2 += rs[k][cl];
         const double var = N > 0.0 ? m2 / N : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
         const float sc = a.gamma[c] * invstd;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinalize a)
 int bn_finalize(const BnFinalize &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.part_sum && a.part_sq && a.win_off && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, a);
     return check_launch("bn_finalize_kernel");
 }
 

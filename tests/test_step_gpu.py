@@ -127,3 +127,46 @@ def test_train_loop_two_steps_match_reference(golden, synth, params):
         for k in sd:
             if "running" in k:
                 np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"final_{tag}_buf/{k}"], rtol=1e-2, atol=5e-3, err_msg=k)   # after two noisy Adam steps
+
+
+def test_reference_style_loop_with_autograd(golden, synth, params):
+    """The reference's own train_loop body, driven through the drop-in modules: W encoder calls, torch.cat, the module
+    forward with the reference signature, torch's CrossEntropyLoss + torch.norm reg, loss.backward(), torch.optim.Adam.
+    Must reproduce the reference's step-1 loss and gradients like the fused path does."""
+    import torch.nn.functional as F
+    enc, att = _models(synth, params, dropout=0.0)
+    g, data = _batch(golden, synth)
+    S = sub("pointNet.amp_step")
+    ce_loss = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).cuda(), reduction="mean", ignore_index=-1)
+    opt_p = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    opt_a = torch.optim.Adam(att.parameters(), lr=1e-3)
+    np.random.seed(1001)
+    x, t = S.augment_batch(data[0].clone(), data[1].clone(), True)          # [B, W, N, 9], [B, W, N]
+    B, W, N, _ = x.shape
+    enc.train(); att.train()
+    opt_p.zero_grad(); opt_a.zero_grad()
+    lo, gl, tp = [], [], []
+    for w in range(W):
+        out, feat_transform = enc(torch.from_numpy(x[:, w]).cuda())
+        lo.append(out[:, :, -64:])
+        gl.append(out[:, 0, :-64].view(-1, 1, 256))
+        tp.append(torch.from_numpy(t[:, w]).cuda())
+    lo, gl, targets_pc = torch.cat(lo, 1), torch.cat(gl, 1), torch.cat(tp, 1)
+    mask = (targets_pc.view(B, -1, W) == -1).all(1)
+    logits, _ = att(gl.transpose(0, 1), lo, data[3].cuda(), [N] * W, mask)
+    ce = ce_loss(logits, targets_pc)
+    eye = torch.eye(64, device="cuda")
+    reg = torch.norm(eye - torch.bmm(feat_transform, feat_transform.transpose(2, 1)))
+    loss = ce + 0.001 * reg
+    loss.backward()
+    opt_p.step(); opt_a.step()
+    assert abs(ce.item() - g["s1_ce"].item()) <= 1e-4 * abs(g["s1_ce"].item())
+    assert abs(reg.item() - g["s1_reg"].item()) <= 1e-4 * abs(g["s1_reg"].item())
+    gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith("s1_") and "_gnorm/" in k))
+    for tag, mod in (("enc", enc), ("att", att)):
+        for k, p in mod.named_parameters():
+            gn = g[f"s1_{tag}_gnorm/{k}"]
+            assert abs(p.grad.double().norm().item() - gn[0]) <= 3e-2 * gn[0] + 1e-5 * gtot, k
+            ps = g[f"s1_{tag}_psum/{k}"]
+            np.testing.assert_allclose(p.detach().double().abs().sum().item(), ps[1], rtol=2e-4,
+                                       atol=2.1e-3 * max(1.0, 0.02 * p.numel()), err_msg=k)
