@@ -1,0 +1,46 @@
+"""collate_seq_padd with the reference's name, output layout and random draws (pointNet/collate_fns.py:4-55):
+every sample is brought to exactly 2048 points per cluster (torch.randint with replacement when it has fewer,
+random.sample when it has more -- the same calls in the same order, so a seeded run collates identically),
+clusters are padded to 9 (data and centroids by replicating the last cluster, targets with -1), and the centroids
+come out through the reference's `.view(-1, 9, 2)` reinterpretation of a [B, 2, 1, 9] tensor.
+Runs in DataLoader workers: CPU only, never touches HIP."""
+import random
+
+import torch
+
+N_POINTS = 2048
+MAX_WINDOWS = 9
+
+
+def _pad_last(t, width, mode):
+    """t [..., w] -> [..., width]; 'replicate' repeats the last slice, otherwise fills with the constant `mode`."""
+    extra = width - t.shape[-1]
+    if extra <= 0:
+        return t
+    if mode == "replicate":
+        tail = t[..., -1:].expand(*t.shape[:-1], extra)
+    else:
+        tail = torch.full((*t.shape[:-1], extra), mode, dtype=t.dtype)
+    return torch.cat([t, tail], dim=-1)
+
+
+def collate_seq_padd(batch):
+    """batch: list of (pc [n, 9, w] float, labels [n, w] int, filename, centroids [2, w] float)
+    -> (data [B, 2048, 9, 9] f32, targets [B, 2048, 9] i64, filenames, centroids [B, 9, 2] f32)."""
+    data, targets, names, cents = [], [], [], []
+    for pc, labels, name, cent in batch:
+        pc = torch.as_tensor(pc).float()
+        labels = torch.as_tensor(labels).long()
+        cent = torch.as_tensor(cent).float().unsqueeze(1)            # [2, 1, w]
+        n = pc.shape[0]
+        if n < N_POINTS:
+            idx = torch.randint(0, n, (N_POINTS,))
+            pc, labels = pc[idx], labels[idx]
+        elif n > N_POINTS:
+            idx = random.sample(range(n), N_POINTS)
+            pc, labels = pc[idx], labels[idx]
+        data.append(_pad_last(pc, MAX_WINDOWS, "replicate"))
+        targets.append(_pad_last(labels, MAX_WINDOWS, -1))
+        cents.append(_pad_last(cent, MAX_WINDOWS, "replicate"))
+        names.append(name)
+    return torch.stack(data, 0), torch.stack(targets, 0), names, torch.stack(cents, 0).view(-1, MAX_WINDOWS, 2)

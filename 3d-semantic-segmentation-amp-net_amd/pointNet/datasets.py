@@ -1,0 +1,96 @@
+"""Datasets of the AMP-Net path with the reference's class names, constructor arguments and return values
+(pointNet/datasets.py:295-460 LidarKmeansDataset, :463-515 LidarDataset4Test).  CPU only (DataLoader workers).
+
+On-disk formats (unchanged): `kmeans_<name>.pt` = torch tensor [n, >=10, w] with columns x, y, HAG, class, I, R, G,
+B, NIR, NDVI, ... (data_proc/3_kmeans.py:116); test files = pickled numpy [n, >=10] rows with the same columns."""
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch.utils import data
+
+NOISE_CLASSES = (30, 7, 2, 8, 13, 14)     # datasets.py:339-350, deleted in this order
+
+
+def segmentation_labels(codes):
+    """ASPRS class codes -> {0 background, 1 tower (15), 2 lines (14), 3 low/medium vegetation (3, 4), 4 high vegetation (5)}
+    (datasets.py:449-458; utils/utils.py:562-570)."""
+    codes = torch.as_tensor(codes)
+    lab = torch.zeros(codes.shape, dtype=torch.long)
+    lab[codes == 15] = 1
+    lab[codes == 14] = 2
+    lab[(codes == 3) | (codes == 4)] = 3
+    lab[codes == 5] = 4
+    return lab
+
+
+class LidarKmeansDataset(data.Dataset):
+    NUM_CLASSIFICATION_CLASSES = 2
+    POINT_DIMENSION = 2
+
+    def __init__(self, dataset_folder, task='classification', number_of_points=None, files=None, fixed_num_points=True,
+                 c_sample=False, sort_kmeans=False, get_centroids=True):
+        self.dataset_folder = dataset_folder
+        self.task = task
+        self.n_points = number_of_points
+        self.files = [f.split('.')[0] for f in files]
+        self.sort_kmeans = sort_kmeans
+        self.get_centroids = get_centroids
+        self.classes_mapping = {}
+        self.constrained_sampling = c_sample
+        self.paths_files = [os.path.join(self.dataset_folder, 'kmeans_' + f + '.pt') for f in self.files]
+
+    def __len__(self):
+        return len(self.paths_files)
+
+    def __getitem__(self, index):
+        """-> (pc [n', 9, w] float32 ndarray, labels [n', w] LongTensor, filename, centroids [2, w] ndarray)
+        for task == 'segmentation' (the AMP-Net path)."""
+        filename = self.paths_files[index]
+        pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True)
+        pc = np.asarray(pc)
+        # a point ROW is dropped from every cluster as soon as one cluster carries a noise code in it
+        # (np.delete on axis 0 with the row indices of np.where over [n, w]; datasets.py:339-350)
+        for code in NOISE_CLASSES:
+            rows = np.where(pc[:, 3, :] == code)[0]
+            pc = np.delete(pc, rows, axis=0)
+        labels = segmentation_labels(pc[:, 3, :])
+        pc = np.concatenate((pc[:, :3, :], pc[:, 4:10, :]), axis=1)
+        pc[:, 0, :] = pc[:, 0, :] * 2 - 1
+        pc[:, 1, :] = pc[:, 1, :] * 2 - 1
+        centroids = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], axis=0) if self.get_centroids else None
+        if self.task != 'segmentation':
+            raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
+        return pc, labels, filename, centroids
+
+
+class LidarDataset4Test(data.Dataset):
+    NUM_CLASSIFICATION_CLASSES = 2
+    POINT_DIMENSION = 2
+
+    def __init__(self, dataset_folder, task='classification', number_of_points=None, files=None, fixed_num_points=True,
+                 c_sample=False):
+        self.dataset_folder = dataset_folder
+        self.task = task
+        self.n_points = number_of_points
+        self.files = files
+        self.fixed_num_points = fixed_num_points
+        self.classes_mapping = {}
+        self.constrained_sampling = c_sample
+        self.paths_files = [os.path.join(self.dataset_folder, f) for f in self.files]
+
+    def __len__(self):
+        return len(self.paths_files)
+
+    def __getitem__(self, index):
+        """-> (pc [n, 10] float32 ndarray: x, y, HAG, I, R, G, B, NIR, NDVI, class code; filename).
+        NOTE: the reference unpickles the file (pickle.load, datasets.py:499-502); only files you wrote yourself
+        should be fed here."""
+        filename = self.paths_files[index]
+        with open(filename, 'rb') as f:
+            pc = np.asarray(pickle.load(f), dtype=np.float32)
+        pc = np.concatenate((pc[:, :3], pc[:, 4:10], pc[:, 3:4]), axis=1)
+        pc[:, 0] = pc[:, 0] * 2 - 1
+        pc[:, 1] = pc[:, 1] * 2 - 1
+        return pc, filename

@@ -94,8 +94,21 @@ def shuffle_clusters(data, labels):
 
 
 # ---- checkpoints (utils/utils.py:422-438): same dict keys, same file naming -------------------------
+def get_cluster_centroid(pc):
+    """pc [n, >=2] tensor -> tensor [2] = (mean x, mean y)   (utils/utils.py:538-543)."""
+    return torch.stack([pc[:, 0].mean(0), pc[:, 1].mean(0)], dim=0)
+
+
+def get_labels(cluster_lists):
+    """list of clusters [n_i, >=10] (column 9 = ASPRS class code) -> list of LongTensor [n_i] with the segmentation
+    labels 0 background, 1 tower, 2 lines, 3 low/medium vegetation, 4 high vegetation (utils/utils.py:546-579)."""
+    from ..pointNet.datasets import segmentation_labels
+    return [segmentation_labels(torch.as_tensor(c).squeeze(0)[:, 9]) for c in cluster_lists]
+
+
 def save_checkpoint_segmen_model(name, task, epoch, epochs_since_improvement, base_pointnet, segmen_model,
-                                 opt_pointnet, opt_segmen, accuracy, batch_size, learning_rate, number_of_points):
+                                 opt_pointnet, opt_segmen, accuracy, batch_size, learning_rate, number_of_points,
+                                 weighing_method=None):
     state = {
         "base_pointnet": base_pointnet.state_dict(),
         "segmen_net": segmen_model.state_dict(),

@@ -1,0 +1,164 @@
+"""CPU tests of the host side: collate / dataset / metrics mirrors against the reference's outputs, the C-ABI
+symbol table, the parameter tables, checkpoints."""
+import ctypes
+import os
+import pickle
+import random
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import sub                           # noqa: E402
+
+
+def test_collate_seq_padd_matches_reference(golden, synth):
+    g = golden("collate")
+    C = sub("pointNet.collate_fns")
+    specs = [(61, 2048, 1), (62, 2048, 3), (63, 1500, 5), (64, 3000, 9), (65, 2048, 9)]
+    batch = []
+    for seed, n, w in specs:
+        win = synth.windows(seed, w, n)
+        pc = np.ascontiguousarray(win.transpose(1, 2, 0))
+        lab = synth.labels_for(win, seed).transpose(1, 0).copy()
+        cent = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], 0).astype(np.float32)
+        batch.append((pc, lab, f"f{seed}", cent))
+    random.seed(5)
+    torch.manual_seed(5)
+    data, tg, names, cents = C.collate_seq_padd(batch)
+    assert list(data.shape) == list(g["data_shape"]) and list(tg.shape) == list(g["tg_shape"])
+    assert names == [f"f{s}" for s, _, _ in specs]
+    np.testing.assert_array_equal(cents.numpy(), g["cents"])                   # incl. the .view(-1, 9, 2) quirk
+    np.testing.assert_array_equal(data[:, ::97].numpy(), g["data_probe"])      # same random draws, same rows
+    np.testing.assert_array_equal(tg[:, ::97].numpy(), g["tg_probe"])
+    np.testing.assert_allclose(data.double().sum(dim=(1, 2)).numpy(), g["data_sum"], rtol=1e-12)
+    np.testing.assert_array_equal(tg.sum(dim=1).numpy(), g["tg_sum"])
+    # padded clusters: targets -1, data = the last real cluster
+    assert (tg[0, :, 1:] == -1).all() and torch.equal(data[0, :, :, 0], data[0, :, :, 8])
+
+
+def test_kmeans_dataset_matches_reference(golden, synth, tmp_path):
+    g = golden("dataset")
+    D = sub("pointNet.datasets")
+    raw = synth.kmeans_file_tensor(71, 96, 3)
+    torch.save(torch.from_numpy(raw), tmp_path / "kmeans_tile71.pt")
+    ds = D.LidarKmeansDataset(str(tmp_path), task="segmentation", number_of_points=2048, files=["tile71.pt"])
+    assert len(ds) == 1
+    pc, lab, fn, cent = ds[0]
+    np.testing.assert_array_equal(pc, g["pc"])
+    np.testing.assert_array_equal(lab.numpy(), g["labels"])
+    np.testing.assert_array_equal(cent, g["centroids"])
+    assert fn.endswith("kmeans_tile71.pt") and pc.shape[0] < 96            # noise rows were dropped
+
+
+def test_test_dataset_and_labels(synth, tmp_path):
+    D = sub("pointNet.datasets")
+    U = sub("utils.utils")
+    raw = synth.kmeans_file_tensor(72, 50, 1)[:, :, 0]                     # [n, 13]
+    with open(tmp_path / "t.pkl", "wb") as f:
+        pickle.dump(raw, f)
+    ds = D.LidarDataset4Test(str(tmp_path), task="segmentation", number_of_points=2048, files=["t.pkl"], fixed_num_points=False)
+    pc, fn = ds[0]
+    assert pc.shape == (50, 10)
+    np.testing.assert_allclose(pc[:, 0], raw[:, 0] * 2 - 1)
+    np.testing.assert_array_equal(pc[:, 9], raw[:, 3])
+    labs = U.get_labels([torch.from_numpy(pc).unsqueeze(0)])
+    want = np.select([raw[:, 3] == 15, raw[:, 3] == 14, (raw[:, 3] == 3) | (raw[:, 3] == 4), raw[:, 3] == 5], [1, 2, 3, 4], 0)
+    np.testing.assert_array_equal(labs[0].numpy(), want)
+    c = U.get_cluster_centroid(torch.from_numpy(pc))
+    np.testing.assert_allclose(c.numpy(), pc[:, :2].mean(0), rtol=1e-6)
+
+
+def test_metrics_match_reference(golden, synth):
+    g = golden("metrics")
+    M = sub("utils.get_metrics")
+    U = sub("utils.utils")
+    preds = torch.from_numpy(synth.randint(51, (4000,), 0, 5))
+    tgt = synth.randint(52, (4000,), 0, 5)
+    tgt[synth.uniform01(53, (4000,)) < 0.2] = -1
+    p2, t2, keep = U.rm_padding(preds, torch.from_numpy(tgt))
+    assert int(keep.sum()) == int(g["n_keep"])
+    for c in range(5):
+        assert M.get_iou_obj(p2, t2, c) == float(g["ious"][c])
+    assert M.get_accuracy(p2, t2, {}, "segmentation")["accuracy"] == float(g["acc"])
+    assert np.isnan(M.get_iou_obj(torch.tensor([0, 0, 1, 1]), torch.tensor([0, 1, 1, 1]), 4))
+
+
+def test_host_augmentation_replays_reference_draws(synth):
+    """augment_batch == the reference's draw order (helpers.replay_augment restates train_loop's host legs)."""
+    from helpers import replay_augment
+    S = sub("pointNet.amp_step")
+    pc, tg, cent, _ = synth.sample_batch(9, 3, 64, max_w=4, w_real=[4, 2, 3])
+    for train in (False, True):
+        want_pc, want_tg = replay_augment(123, pc, tg, train)
+        np.random.seed(123)
+        x, t = S.augment_batch(torch.from_numpy(pc.copy()), torch.from_numpy(tg.copy()), train)
+        np.testing.assert_array_equal(x, want_pc.transpose(0, 3, 1, 2))
+        np.testing.assert_array_equal(t, want_tg.transpose(0, 2, 1))
+
+
+# ---- the C ABI: every symbol the header declares is exported; tables match the Python side -------------------
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ampnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ampnet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = sub("_lib")
+    lib = L.lib()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ampnet_hip.h but not exported"
+    assert lib.ampnet_abi_version() == L.ABI_VERSION
+
+
+def test_parameter_tables_match_library(params):
+    lib = sub("_lib").lib()
+    lib.ampnet_table_name.restype = ctypes.c_char_p
+    lib.ampnet_table_numel.restype = ctypes.c_long
+    for t, table in enumerate((params.ENC_PARAMS, params.ENC_BUFFERS, params.HEAD_PARAMS, params.HEAD_BUFFERS)):
+        assert lib.ampnet_table_count(t) == len(table)
+        for i, (name, shape) in enumerate(table.items()):
+            assert lib.ampnet_table_name(t, i).decode() == name
+            assert lib.ampnet_table_numel(t, i) == params.numel(shape)
+
+
+def test_cpu_tensors_fail_loudly(synth):
+    """No CPU fallback: the HIP path refuses host tensors instead of computing something else."""
+    U = sub("utils.utils")
+    L = sub("_lib")
+    with pytest.raises(L.AmpnetError):
+        U.fps_indices(torch.from_numpy(synth.clouds(1, 1, 64)[0]), 8)
+    M = sub("pointNet.model.pointnetAtt")
+    with pytest.raises(NotImplementedError):
+        M.BasePointNet(point_dimension=2, device="cpu")
+    enc = M.BasePointNet(point_dimension=3, return_local_features=True, device="cpu")
+    with pytest.raises(L.AmpnetError):
+        enc(torch.zeros(2, 64, 9))
+
+
+def test_checkpoint_roundtrip_keys(tmp_path, params):
+    M = sub("pointNet.model.pointnetAtt")
+    U = sub("utils.utils")
+    enc = M.BasePointNet(point_dimension=3, return_local_features=True, device="cpu")
+    att = M.SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, device="cpu")
+    o1 = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    o2 = torch.optim.Adam(att.parameters(), lr=1e-3)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        U.save_checkpoint_segmen_model("t", "segmentation", 3, 0, enc, att, o1, o2, 0.5, 32, 1e-3, 2048, None)
+        ck = torch.load("pointNet/checkpoints/model_t.pth", weights_only=True)
+    finally:
+        os.chdir(cwd)
+    assert set(ck) == {"base_pointnet", "segmen_net", "opt_pointnet", "opt_segmen", "task", "batch_size", "lr",
+                       "number_of_points", "epoch", "epochs_since_improvement", "accuracy"}
+    enc2 = M.BasePointNet(point_dimension=3, return_local_features=True, device="cpu")
+    enc2.load_state_dict(ck["base_pointnet"])                  # strict: every reference key present, nothing extra
+    assert torch.equal(enc2.conv_6.weight, enc.conv_6.weight)
