@@ -1,0 +1,92 @@
+"""AMP-Net inference driver on the HIP path: same function name, arguments and outputs as the reference's test()
+(pointNet/self-attention/test_pointnet_att_segmen.py:31-284): one file per step, its pre-computed constrained
+k-means clusters read from `<cluster_dir>/<file>_clusters_list.pkl` / `_centroids.pkl` (default `k_means_25/`),
+per-file accuracy and per-class IoU, a CSV row appended to <out_path>/../IoU-results-v2.csv.
+
+The reference pushes every cluster (they have different sizes) through the encoder in a Python loop and repeats /
+concatenates the attention tokens per point; here all clusters of a file are ONE ragged launch sequence."""
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from ..utils.get_metrics import get_accuracy, get_iou_obj
+from ..utils.utils import get_labels
+from .datasets import LidarDataset4Test
+from .model.pointnetAtt import BasePointNet, SegmentationWithAttention
+
+CLASS_KEYS = ['bckg', 'tower', 'cables', 'low_veg', 'high_veg']
+
+
+def _load_list(path):
+    """The cluster pickles are lists of tensors.  torch's restricted unpickler reads files written with torch.save;
+    files written by the reference's kmeans_clustering (plain pickle.dump, utils/utils.py:526-533) need pickle.load,
+    which executes what the file says: only feed files you produced yourself."""
+    try:
+        return torch.load(path, weights_only=True)
+    except Exception:
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+
+
+def segment_file(base_pointnet, segmen_net, clusters_list, centroids, device):
+    """clusters_list: list of [n_i, >=10] tensors (cols 0..8 features, col 9 class code); centroids [W, 2]
+    -> (preds [sum n_i] int64 cpu, targets [sum n_i] int64 cpu)."""
+    targets = torch.cat(get_labels([c.clone() for c in clusters_list]), dim=0)
+    sizes = [int(c.shape[0]) for c in clusters_list]
+    rows = torch.cat([torch.as_tensor(c)[:, :9].float() for c in clusters_list], dim=0).to(device)
+    cent = torch.as_tensor(centroids).float().reshape(1, len(sizes), 2).to(device)
+    with torch.no_grad():
+        local, glob, _ = base_pointnet.forward_windows(rows, np_cluster=sizes)
+        logits, preds, _ = segmen_net.forward_rows(glob, local, cent, sizes, None, want_preds=True)
+    return preds.reshape(-1).cpu(), targets.reshape(-1)
+
+
+def test(dataset_path, out_path, n_points, number_of_workers, model_checkpoint, path_list_files, cluster_dir='k_means_25',
+         device='cuda'):
+    start = time.time()
+    device = torch.device(device)
+    checkpoint = torch.load(model_checkpoint, map_location=device, weights_only=True)
+    with open(os.path.join(path_list_files, 'test_seg_files.txt')) as f:
+        test_files = f.read().splitlines()
+    ds = LidarDataset4Test(dataset_path, task='segmentation', number_of_points=n_points, files=test_files, fixed_num_points=False)
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=number_of_workers, drop_last=False)
+    base_pointnet = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device=device)
+    segmen_net = SegmentationWithAttention(256, 8, local_dim=64, num_classes=5, device=device)
+    base_pointnet.load_state_dict(checkpoint['base_pointnet'])
+    segmen_net.load_state_dict(checkpoint['segmen_net'])
+    base_pointnet.eval()
+    segmen_net.eval()
+    total_params = sum(p.numel() for p in base_pointnet.parameters()) + sum(p.numel() for p in segmen_net.parameters())
+    print(f"Total Trainable Params: {total_params}")
+    iou = {k: [] for k in CLASS_KEYS}
+    accuracy = []
+    for pc, file_name in loader:
+        name = file_name[0].split('/')[-1].split('.')[0]
+        clusters = _load_list(os.path.join(cluster_dir, name + '_clusters_list.pkl'))
+        centroids = _load_list(os.path.join(cluster_dir, name + '_centroids.pkl'))
+        preds, targets = segment_file(base_pointnet, segmen_net, clusters, torch.as_tensor(centroids), device)
+        accuracy.append(get_accuracy(preds.numpy(), targets.numpy(), {}, 'segmentation')['accuracy'])
+        present = set(targets.numpy().reshape(-1).tolist())
+        per = [get_iou_obj(preds, targets, c) if c in present else None for c in range(5)]
+        for c, k in enumerate(CLASS_KEYS):
+            if per[c] is not None:
+                iou[k].append(per[c])
+        miou = np.nanmean(np.array([per[1], per[2], per[3], per[4], per[0]], dtype=np.float64))
+        print([per[1], per[2], miou])
+    iou_arr = [np.mean(iou['tower']), np.mean(iou['low_veg']), np.mean(iou['high_veg']), np.mean(iou['bckg']), np.mean(iou['cables'])]
+    mean_iou = float(np.mean(iou_arr))
+    print('mean_iou: ', mean_iou, ' accuracy: ', float(np.mean(accuracy)))
+    minutes = round((time.time() - start) / 60, 3)
+    print("--- TOTAL TIME: %s min ---" % minutes)
+    model_name = model_checkpoint.split('/')[-1].split('.')[0]
+    out_path = os.path.join(out_path, 'preds_Att')
+    os.makedirs(out_path + '/figures', exist_ok=True)
+    with open(os.path.join(os.path.dirname(out_path), 'IoU-results-v2.csv'), 'a') as fid:
+        fid.write('%s,%s,%s,%s,%s,%s,%s,%s,%s,%s,%s\n' % (
+            model_name, n_points, round(float(np.mean(iou['tower'])), 3), round(float(np.mean(iou['low_veg'])), 3),
+            round(float(np.mean(iou['high_veg'])), 3), round(float(np.mean(iou['cables'])), 3), round(float(np.mean(iou['bckg'])), 3),
+            round(mean_iou, 4), round(float(np.mean(accuracy)), 3), total_params, minutes))
+    return dict(mean_iou=mean_iou, accuracy=float(np.mean(accuracy)), iou={k: float(np.mean(v)) if v else float('nan') for k, v in iou.items()})

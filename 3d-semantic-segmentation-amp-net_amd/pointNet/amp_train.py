@@ -1,0 +1,125 @@
+"""AMP-Net training driver on the HIP path: same function name, arguments, files read and files written as the
+reference's train_att (pointNet/self-attention/train_pointnet-attention.py:29-334):
+
+  reads   <path_list_files>/train_seg_files.txt, val_seg_files.txt; <dataset_folder>/kmeans_<name>.pt
+  trains  BasePointNet(3, True, 256) + SegmentationWithAttention(256, 8, 5, local_dim=64), CE weights [1,2,2,1,1],
+          2 x Adam(lr), MultiStepLR milestones [150, 250, 350] gamma 0.5 stepped per epoch
+  writes  pointNet/checkpoints/model_<name>.pth (same dict keys) whenever the mean validation loss improves.
+
+Data parallel: launched under torch.distributed.run (one process per GPU) every rank trains on a rank-strided
+shard of the file list and gradients are all-reduced per step (RCCL); rank 0 logs and writes checkpoints."""
+import datetime
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..trainer import FusedAdam, shard_indices
+from ..utils.get_metrics import get_accuracy, get_iou_obj
+from ..utils.utils import rm_padding, save_checkpoint_segmen_model
+from .amp_step import train_loop
+from .collate_fns import collate_seq_padd
+from .datasets import LidarKmeansDataset
+from .model.pointnetAtt import BasePointNet, SegmentationWithAttention
+
+GLOBAL_FEAT_SIZE = 256
+ATT_HEADS = 8
+IOU_NAMES = ['bckg', 'tower', 'cables', 'low_veg', 'high_veg']
+
+
+def _dist_setup():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return dist.get_rank(), world, local
+    return 0, 1, 0
+
+
+def _epoch(loader, train, pointnet, att_net, opt_p, opt_a, ce_loss, epoch):
+    sums = dict(loss=[], ce=[], reg=[], acc=[])
+    ious = {k: [] for k in IOU_NAMES}
+    for data in loader:
+        metrics, targets, preds, _ = train_loop(data, opt_p, opt_a, ce_loss, pointnet, att_net, None, 'segmentation', train, epoch, 0)
+        preds, targets, _ = rm_padding(preds.reshape(-1), targets.reshape(-1))
+        sums['acc'].append(get_accuracy(preds, targets, {}, 'segmentation')['accuracy'])
+        for c, name in enumerate(IOU_NAMES):
+            ious[name].append(get_iou_obj(preds, targets, c))
+        sums['loss'].append(metrics['loss'].item())
+        sums['ce'].append(metrics['ce_loss'].item())
+        sums['reg'].append(metrics['reg_loss'].item())
+    out = {k: float(np.mean(v)) if v else float('nan') for k, v in sums.items()}
+    out.update({'iou_' + k: float(np.nanmean(v)) if v else float('nan') for k, v in ious.items()})
+    return out
+
+
+def train_att(task, dataset_folder, path_list_files, output_folder, n_points, batch_size, epochs, learning_rate,
+              weighing_method='EFS', beta=0.999, number_of_workers=4, model_checkpoint=None, device='cuda'):
+    if task != 'segmentation':
+        raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
+    start = time.time()
+    rank, world, local = _dist_setup()
+    device = torch.device('cuda', local)
+    with open(os.path.join(path_list_files, 'train_seg_files.txt')) as f:
+        train_files = f.read().splitlines()
+    with open(os.path.join(path_list_files, 'val_seg_files.txt')) as f:
+        val_files = f.read().splitlines()
+    if world > 1:
+        train_files = [train_files[i] for i in shard_indices(len(train_files), rank, world)]
+        val_files = [val_files[i] for i in shard_indices(len(val_files), rank, world)]
+    name = 'ATT' + 'g' + str(GLOBAL_FEAT_SIZE) + 'w100' + 'xyz'
+    train_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=train_files)
+    val_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=val_files)
+    mk = lambda ds: torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=number_of_workers,   # noqa: E731
+                                                drop_last=True, collate_fn=collate_seq_padd)
+    train_loader, val_loader = mk(train_ds), mk(val_ds)
+    if rank == 0:
+        print(f'Dataset folder: {dataset_folder}\nSamples for training: {len(train_ds)} (per rank), validation: {len(val_ds)}')
+
+    pointnet = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=GLOBAL_FEAT_SIZE, device=device)
+    att_net = SegmentationWithAttention(GLOBAL_FEAT_SIZE, ATT_HEADS, num_classes=5, local_dim=64, device=device)
+    c_weights = torch.FloatTensor([1, 2, 2, 1, 1]).to(device)
+    ce_loss = torch.nn.CrossEntropyLoss(weight=c_weights, reduction='mean', ignore_index=-1)
+    opt_p = FusedAdam(pointnet.parameters(), lr=learning_rate)
+    opt_a = FusedAdam(att_net.parameters(), lr=learning_rate)
+    sched = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[150, 250, 350], gamma=0.5) for o in (opt_p, opt_a)]
+    best_vloss, epoch_ini, since = 1_000_000., 0, 0
+    if model_checkpoint:
+        ck = torch.load(model_checkpoint, map_location=device, weights_only=True)
+        pointnet.load_state_dict(ck['base_pointnet'])
+        att_net.load_state_dict(ck['segmen_net'])
+        opt_p.load_state_dict(ck['opt_pointnet'])
+        opt_a.load_state_dict(ck['opt_segmen'])
+        batch_size, learning_rate, epoch_ini = ck['batch_size'], ck['lr'], ck['epoch']
+    if world > 1:                                      # same start on every rank
+        import torch.distributed as dist
+        for m in (pointnet, att_net):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0)
+    history = []
+    for epoch in range(epoch_ini, epochs):
+        t0 = time.time()
+        tr = _epoch(train_loader, True, pointnet, att_net, opt_p, opt_a, ce_loss, epoch)
+        with torch.no_grad():
+            va = _epoch(val_loader, False, pointnet, att_net, opt_p, opt_a, ce_loss, epoch)
+        for s in sched:
+            s.step()
+        history.append((tr, va))
+        if rank == 0:
+            print(f"epoch {epoch}: train loss {tr['loss']:.4f} acc {tr['acc']:.3f} | val loss {va['loss']:.4f} acc {va['acc']:.3f} "
+                  f"iou tower {va['iou_tower']:.3f} | {time.time() - t0:.1f} s", flush=True)
+        if va['loss'] < best_vloss:
+            best_vloss, since = va['loss'], 0
+            if rank == 0:
+                stamp = datetime.datetime.now().strftime("%m-%d-%H:%M")
+                save_checkpoint_segmen_model(stamp + name, task, epoch, since, pointnet, att_net, opt_p, opt_a, va['acc'],
+                                             batch_size, learning_rate, n_points, weighing_method)
+        else:
+            since += 1
+    if rank == 0:
+        print("--- TOTAL TIME: %s h ---" % (round((time.time() - start) / 3600, 3)))
+    return history
