@@ -31,8 +31,8 @@ __device__ __forceinline__ int pidx_of_b(int q, int n_slots, int Q, int slot_maj
 // ----------------------------------------------------------------------------------------------------
 // pw_dgrad
 // ----------------------------------------------------------------------------------------------------
-template <int K, int NT>
-__global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
+template <int K, int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
 {
     constexpr int CB = 32 * NT;
     constexpr int LDW = K + 4;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             // shared weight W[k][j] (torch [cout_l = K][cin_l]): transpose while staging
             // consecutive lanes take consecutive k: the LDS writes are conflict-free, the 16-byte global reads are
             // strided but L2-resident (the whole weight is <= 128 KB and every workgroup reads it)
-            for (int e = tid; e < K * (CB / 4); e += BW_NW * 64) {
+            for (int e = tid; e < K * (CB / 4); e += NW * 64) {
                 const int k = e % K, j4 = e / K;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cb0 + 4 * j4 < a.cp) v = *reinterpret_cast<const f32x4 *>(a.W + (size_t)k * a.ldw + cb0 + 4 * j4);
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             }
         } else {
             const float *Wg = a.W + (size_t)pidx * a.w_win_stride;   // T[j][k], k contiguous, K columns
-            for (int e = tid; e < CB * (K / 4); e += BW_NW * 64) {
+            for (int e = tid; e < CB * (K / 4); e += NW * 64) {
                 const int j = e / (K / 4), k4 = e % (K / 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cb0 + j < a.cp) v = *reinterpret_cast<const f32x4 *>(Wg + (size_t)(cb0 + j) * K + 4 * k4);
                 *reinterpret_cast<f32x4 *>(sW + j * LDW + 4 * k4) = v;
             }
         }
-        for (int e = tid; e < K; e += BW_NW * 64) {
+        for (int e = tid; e < K; e += NW * 64) {
             sP[e] = has_bn ? a.g.P1[(size_t)slot * K + e] : 1.0f;
             sP[K + e] = has_bn ? a.g.P2[(size_t)slot * K + e] : 0.0f;
             sP[2 * K + e] = has_bn ? a.g.P3[(size_t)slot * K + e] : 0.0f;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
 
     int tile = wave;
     if (tile < ntiles) load_blk(tile, 0, dy_cur, z_cur);
-    for (; tile < ntiles; tile += BW_NW) {
+    for (; tile < ntiles; tile += NW) {
         const int row0 = row_begin + tile * 32;
         const int valid = min(32, row_end - row0);
         const int arow = row0 + min(r, valid - 1);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             {
                 int ptile = tile, pkb = kb + 1;
                 if (pkb == NBLK) {
-                    ptile = tile + BW_NW;
+                    ptile = tile + NW;
                     pkb = 0;
                 }
                 if (ptile < ntiles) load_blk(ptile, pkb, dy_nxt, z_nxt);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
 
     if (!do_part) return;
     __syncthreads();
-    float *red = smem;     // [BW_NW][CB][2]
+    float *red = smem;     // [NW][CB][2]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float oa = __shfl_xor(s_a[t], 32), ob = __shfl_xor(s_b[t], 32);
@@ -224,12 +224,12 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
         }
     }
     __syncthreads();
-    for (int c = tid; c < CB; c += BW_NW * 64) {
+    for (int c = tid; c < CB; c += NW * 64) {
         const int col = cb0 + c;
         if (col >= a.cp) continue;
         float sa = 0.f, sb = 0.f;
 #pragma unroll
-        for (int w = 0; w < BW_NW; ++w) {
+        for (int w = 0; w < NW; ++w) {
             sa += red[(w * CB + c) * 2 + 0];
             sb += red[(w * CB + c) * 2 + 1];
         }
@@ -239,15 +239,15 @@ __global__ __launch_bounds__(BW_NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
     }
 }
 
-template <int K, int NT>
+template <int K, int NT, int NW>
 static int launch_dgrad(const PwDgrad &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = (size_t)(CB * (K + 4) + 5 * K) * sizeof(float);
-    constexpr size_t lds_red = (size_t)BW_NW * CB * 2 * sizeof(float);
+    constexpr size_t lds_red = (size_t)NW * CB * 2 * sizeof(float);
     constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
     static bool attr_set = false;
-    auto kern = pw_dgrad_kernel<K, NT>;
+    auto kern = pw_dgrad_kernel<K, NT, NW>;
     if (!attr_set) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -259,7 +259,7 @@ static int launch_dgrad(const PwDgrad &a, hipStream_t st)
     snprintf(name, sizeof(name), "pw_dgrad<%d,%d>%s", K, CB, a.g.dy ? "" : "+sparse");
     const double rows = (double)a.rows_hint;
     ProfScope prof(name, 2.0 * rows * K * a.cp, rows * 4.0 * ((a.g.dy ? K : 0) + (a.g.P1 ? K : 0) + (a.prev.z ? 2.0 : 1.0) * a.cp), st);
-    hipLaunchKernelGGL(kern, dim3(a.chunks, a.Q, cdiv(a.cp, CB)), dim3(BW_NW * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.chunks, a.Q, cdiv(a.cp, CB)), dim3(NW * 64), lds, st, a);
     return check_launch("pw_dgrad_kernel");
 }
 
@@ -270,15 +270,15 @@ int pw_dgrad(const PwDgrad &a, hipStream_t st)
     AMPNET_REQUIRE(!a.g.P1 || (a.g.P2 && a.g.P3 && a.g.z), "pw_dgrad: BatchNorm constants incomplete");
     AMPNET_REQUIRE(a.cp >= 1 && a.cp % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_dgrad: cp / ldw must be multiples of 4");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.z), "pw_dgrad: partial sums need the previous layer");
-    int nt = a.cp > 64 ? 4 : (a.cp > 32 ? 2 : 1);
-    if (a.g.C == 256 && nt == 4) nt = 2;      // 128 x 260 floats of weights would leave one workgroup per CU
+    const int nt = a.cp > 64 ? 4 : (a.cp > 32 ? 2 : 1);
     switch (a.g.C) {
     case 64:
-        return nt == 4 ? launch_dgrad<64, 4>(a, st) : (nt == 2 ? launch_dgrad<64, 2>(a, st) : launch_dgrad<64, 1>(a, st));
+        return nt == 4 ? launch_dgrad<64, 4, 4>(a, st) : (nt == 2 ? launch_dgrad<64, 2, 4>(a, st) : launch_dgrad<64, 1, 4>(a, st));
     case 128:
-        return nt == 4 ? launch_dgrad<128, 4>(a, st) : (nt == 2 ? launch_dgrad<128, 2>(a, st) : launch_dgrad<128, 1>(a, st));
+        return nt == 4 ? launch_dgrad<128, 4, 4>(a, st) : (nt == 2 ? launch_dgrad<128, 2, 4>(a, st) : launch_dgrad<128, 1, 4>(a, st));
     case 256:
-        return nt == 4 ? launch_dgrad<256, 4>(a, st) : (nt == 2 ? launch_dgrad<256, 2>(a, st) : launch_dgrad<256, 1>(a, st));
+        // 128 x 260 floats of weights = 133 KB of LDS = one workgroup per CU: give that workgroup 8 waves
+        return nt == 4 ? launch_dgrad<256, 4, 8>(a, st) : (nt == 2 ? launch_dgrad<256, 2, 4>(a, st) : launch_dgrad<256, 1, 4>(a, st));
     default:
         return fail(AMPNET_E_ARG, "pw_dgrad: K=%d not in {64,128,256}", a.g.C);
     }
