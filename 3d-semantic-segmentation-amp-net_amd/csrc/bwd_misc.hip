@@ -97,8 +97,9 @@ int bn_param_grads(const BnGradItem *items, int n, hipStream_t st)
 }
 
 // ----------------------------------------------------------------------------------------------------
-// pool_bwd: block = (slot, 64 channels); loops the slot's windows (the only rows with a gradient are the
-// argmax rows), so the whole BatchNorm backward reduction of the pooled layer is B gathers per channel.
+// pool_bwd: block = (slot, 64 channels); loops the slot's windows.  The only rows with a gradient are the argmax
+// rows and the forward kept their pre-BatchNorm values (zext), so the whole BatchNorm-backward reduction of the
+// pooled layer is B table look-ups per channel: the [rows, 256] output is never needed again.
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
 {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
         const int row = a.arg[(size_t)q * a.C + c];
         float d = 0.f;
         if (row >= 0) {
-            const float zv = a.z[(size_t)row * a.C + c];
+            const float zv = a.zext[(size_t)q * a.C + c];
             if (fmaf(zv, sc, sh) > 0.f) {
                 d = a.d_pooled[(size_t)prow * a.C + c];
                 A += (double)d;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
 
 int pool_bwd(const PoolBwd &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.d_pooled && a.arg && a.z && a.scale && a.shift && a.mean && a.invstd && a.win_off && a.dpm && a.P1 && a.P2 && a.P3 && a.slot_ab, "pool_bwd: null pointer");
+    AMPNET_REQUIRE(a.d_pooled && a.arg && a.zext && a.scale && a.shift && a.mean && a.invstd && a.win_off && a.dpm && a.P1 && a.P2 && a.P3 && a.slot_ab, "pool_bwd: null pointer");
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64), 0, st, a);
     return check_launch("pool_bwd_kernel");
 }
@@ -414,4 +415,218 @@ int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, hip
     hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots);
     return check_launch("transpose64_kernel");
 }
+}  // namespace ampnet
+
+namespace ampnet {
+
+// ----------------------------------------------------------------------------------------------------
+// sparse_rows: one workgroup per window.  Channels that share an argmax row are merged (in channel order, so the sums
+// are reproducible); the merged rows (P1 dy) W go to srows, rowmap points the window's rows at them.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sparse_rows_kernel(SparseRows a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sS = smem;                                         // [C][cp]
+    int *sArg = reinterpret_cast<int *>(smem + a.C * a.cp);   // [C]
+    float *sCoef = reinterpret_cast<float *>(sArg + a.C);     // [C]
+    int *sIdx = reinterpret_cast<int *>(sCoef + a.C);         // [C] compact row of the channel
+    __shared__ int s_unique;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+    const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+    for (int c = tid; c < a.C; c += 256) {
+        const int r = a.arg[(size_t)q * a.C + c];
+        sArg[c] = r;
+        sCoef[c] = r >= 0 ? a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c] : 0.f;
+    }
+    __syncthreads();
+    // compact row index per channel, in channel order: first[c] = lowest channel with the same argmax row; the owners
+    // (first[c] == c) are numbered by a block-wide prefix count (ballot + popcount per wave, 4 wave totals in LDS)
+    __shared__ int s_wave_cnt[4];
+    int *sFirst = sIdx;                       // reuse: filled with `first`, then overwritten with the compact index
+    {
+        const int c = tid;                    // C <= 256 = blockDim
+        int first = -1;
+        if (c < a.C && sArg[c] >= 0) {
+            first = c;
+            for (int p = 0; p < c; ++p)
+                if (sArg[p] == sArg[c]) {
+                    first = p;
+                    break;
+                }
+        }
+        const bool owner = first == c && c < a.C;
+        const unsigned long long bal = __ballot(owner);
+        const int lane = tid & 63, wv = tid >> 6;
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += s_wave_cnt[w];
+        if (tid == 0) s_unique = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        __syncthreads();
+        // owners publish their compact index; the others read their owner's
+        int *sOwn = reinterpret_cast<int *>(sS);          // [C] scratch (sS is zeroed afterwards)
+        if (owner) sOwn[c] = base + before;
+        __syncthreads();
+        if (c < a.C) sFirst[c] = first >= 0 ? sOwn[first] : -1;
+    }
+    __syncthreads();
+    const int nu = s_unique;
+    for (int e = tid; e < nu * a.cp; e += 256) sS[e] = 0.f;
+    __syncthreads();
+    if (tid < a.cp) {
+        const int k = tid;
+#pragma unroll 4
+        for (int c = 0; c < a.C; ++c) {
+            const int i = sIdx[c];
+            const float w = a.W[(size_t)c * a.cp + k];
+            if (i >= 0) sS[i * a.cp + k] = fmaf(sCoef[c], w, sS[i * a.cp + k]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nu * a.cp; e += 256) a.srows[(size_t)q * a.C * a.cp + e] = sS[e];
+    for (int c = tid; c < a.C; c += 256)
+        if (sIdx[c] >= 0) a.srow_row[(size_t)q * a.C + sIdx[c]] = sArg[c];      // same value from every channel of a merged row
+    if (tid == 0) a.srow_cnt[q] = nu;
+}
+
+// one workgroup per window, thread = column; walks the window's merged rows in order (reproducible sums)
+__global__ __launch_bounds__(128) void sparse_fix_kernel(SparseFix a)
+{
+    const int q = blockIdx.x, k = threadIdx.x;
+    if (k >= a.cp) return;
+    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+    const float sc = a.s_prev[(size_t)slot * a.cp + k], sh = a.t_prev[(size_t)slot * a.cp + k];
+    const float mu = a.mean_prev[(size_t)slot * a.cp + k], is = a.invstd_prev[(size_t)slot * a.cp + k];
+    const int n = a.srow_cnt[q];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+        const int row = a.srow_row[(size_t)q * a.C + i];
+        const float zv = a.z_prev[(size_t)row * a.cp + k];
+        const float sv = a.srows[((size_t)q * a.C + i) * a.cp + k];
+        const float v = fmaf(zv, sc, sh) > 0.f ? sv : 0.f;
+        a.out[(size_t)row * a.cp + k] += v;            // each row appears once per window: no conflict
+        sa += v;
+        sb = fmaf(v, (zv - mu) * is, sb);
+    }
+    const size_t o = (size_t)(q * a.part_chunks + a.slot_idx) * a.cp + k;
+    a.part_a[o] = sa;
+    a.part_b[o] = sb;
+}
+
+int sparse_fix(const SparseFix &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.srows && a.srow_row && a.srow_cnt && a.z_prev && a.s_prev && a.t_prev && a.mean_prev && a.invstd_prev && a.out && a.part_a && a.part_b, "sparse_fix: null pointer");
+    AMPNET_REQUIRE(a.cp <= 128, "sparse_fix: cp=%d", a.cp);
+    hipLaunchKernelGGL(sparse_fix_kernel, dim3(a.Q), dim3(128), 0, st, a);
+    return check_launch("sparse_fix_kernel");
+}
+
+int sparse_rows(const SparseRows &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.srows && a.srow_row && a.srow_cnt, "sparse_rows: null pointer");
+    AMPNET_REQUIRE(a.cp <= 256 && a.C <= 256, "sparse_rows: C=%d cp=%d", a.C, a.cp);
+    const size_t lds = (size_t)(a.C * a.cp + 3 * a.C) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "sparse_rows: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sparse_rows_kernel, dim3(a.Q), dim3(256), lds, st, a);
+    return check_launch("sparse_rows_kernel");
+}
+
+// one thread per (j, k) of G (and row j == cp for c0), loop over the C contracted channels
+__global__ __launch_bounds__(256) void slot_mats_kernel(const float *__restrict__ W, const float *__restrict__ P2, const float *__restrict__ P3,
+                                                       int C, int cp, float *__restrict__ G, float *__restrict__ c0)
+{
+    const int s = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= (cp + 1) * cp) return;
+    const int j = e / cp, k = e % cp;
+    float acc = 0.f;
+    if (j < cp) {
+        for (int c = 0; c < C; ++c) acc = fmaf(W[(size_t)c * cp + j] * P2[(size_t)s * C + c], W[(size_t)c * cp + k], acc);
+        G[((size_t)s * cp + j) * cp + k] = acc;
+    } else {
+        for (int c = 0; c < C; ++c) acc = fmaf(P3[(size_t)s * C + c], W[(size_t)c * cp + k], acc);
+        c0[(size_t)s * cp + k] = acc;
+    }
+}
+
+int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st)
+{
+    hipLaunchKernelGGL(slot_mats_kernel, dim3(cdiv((cp + 1) * cp, 256), n_slots), dim3(256), 0, st, W, P2, P3, C, cp, G, c0);
+    return check_launch("slot_mats_kernel");
+}
+
+__global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ part, int Q, int chunks, int n_slots, int n_el,
+                                                          float *__restrict__ out)
+{
+    const int s = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_el) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int q = s; q < Q; q += n_slots)
+        for (int ch = 0; ch < chunks; ch += 2) {
+            a0 += part[(size_t)(q * chunks + ch) * n_el + e];
+            if (ch + 1 < chunks) a1 += part[(size_t)(q * chunks + ch + 1) * n_el + e];
+        }
+    out[(size_t)s * n_el + e] = a0 + a1;
+}
+
+int reduce_slots(const float *part, int Q, int chunks, int n_slots, int n_el, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(cdiv(n_el, 256), n_slots), dim3(256), 0, st, part, Q, chunks, n_slots, n_el, out);
+    return check_launch("reduce_slots_kernel");
+}
+
+// block = output channel c, thread = input channel k
+__global__ __launch_bounds__(128) void pooled_wgrad_kernel(PooledWgrad a)
+{
+    __shared__ float sW[256];
+    extern __shared__ int sDyn[];         // [Q] argmax row (clamped to 0), [Q] coefficient (as float bits)
+    int *sRow = sDyn;
+    float *sCoef = reinterpret_cast<float *>(sDyn + a.Q);
+    const int c = blockIdx.x, k = threadIdx.x;
+    for (int j = k; j < a.cp; j += 128) sW[j] = a.W[(size_t)c * a.cp + j];
+    for (int q = k; q < a.Q; q += 128) {
+        const int r = a.arg[(size_t)q * a.C + c];
+        const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+        const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+        sRow[q] = r < 0 ? 0 : r;
+        sCoef[q] = r < 0 ? 0.f : a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c];
+    }
+    __syncthreads();
+    if (k >= a.cp) return;
+    float acc = 0.f;
+    for (int s = 0; s < a.n_slots; ++s) {
+        float m = 0.f;
+        const float *g = a.gram + (size_t)s * a.cp * a.cp;
+#pragma unroll 8
+        for (int j = 0; j < a.cp; ++j) m = fmaf(sW[j], g[(size_t)j * a.cp + k], m);
+        acc = fmaf(a.P2[(size_t)s * a.C + c], m, acc);
+        acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
+    }
+    // sparse part: gathers of the argmax rows, independent loads (no branches) so that they pipeline
+    const float *__restrict__ zp = a.z_prev;
+#pragma unroll 8
+    for (int q = 0; q < a.Q; ++q) {
+        const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+        const float av = fmaxf(fmaf(zp[(size_t)sRow[q] * a.cp + k], a.s_prev[(size_t)slot * a.cp + k], a.t_prev[(size_t)slot * a.cp + k]), 0.f);
+        acc = fmaf(sCoef[q], av, acc);
+    }
+    a.dW[(size_t)c * a.cp + k] = acc;
+}
+
+int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.W && a.P1 && a.P2 && a.P3 && a.gram && a.asum && a.arg && a.dpm && a.z_prev && a.s_prev && a.t_prev && a.dW, "pooled_wgrad: null pointer");
+    AMPNET_REQUIRE(a.cp <= 128 && a.Q * 2 * sizeof(int) <= 48 * 1024, "pooled_wgrad: cp=%d Q=%d", a.cp, a.Q);
+    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3(a.C), dim3(128), a.Q * 2 * sizeof(int), st, a);
+    return check_launch("pooled_wgrad_kernel");
+}
+
 }  // namespace ampnet

@@ -36,6 +36,7 @@ struct EncWs {
     // pooled / FC activations, [Q, C] (rows slot-major), transforms
     float *pool_t, *z_tf1, *z_tf2, *T3, *pool_f, *z_ff1, *z_ff2;
     int *arg_t, *arg_f, *arg_c;        // [Q, 256] row index of the pooled extreme
+    float *zext_t, *zext_f, *zext_c;   // [Q, 256] its pre-BatchNorm value (all the backward needs of the 256-channel layers)
     int *fc_off;                       // [n_slots + 1]
     float *part_sum, *part_sq, *part_max, *part_min;   // [Q * chunks, 256]
     int *part_amax, *part_amin;

@@ -54,18 +54,19 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     Carver c{reinterpret_cast<char *>(base)};
     const size_t R = (size_t)s.R, Q = (size_t)s.Q;
     if (s.train) {
+        // the 256-channel pooled layers are not stored in train mode either: their backward is algebraic (encoder_bwd.hip)
         ws.z_t1 = c.take<float>(R * 64);
         ws.z_t2 = c.take<float>(R * 128);
-        ws.z_t3 = c.take<float>(R * 256);
+        ws.z_t3 = nullptr;
         ws.z_c1 = c.take<float>(R * 64);
         ws.z_c2 = c.take<float>(R * 64);
         ws.z_f1 = c.take<float>(R * 64);
         ws.z_f2 = c.take<float>(R * 128);
-        ws.z_f3 = c.take<float>(R * 256);
+        ws.z_f3 = nullptr;
         ws.z_c3 = c.take<float>(R * 64);
         ws.z_c4 = c.take<float>(R * 128);
         ws.z_c5 = c.take<float>(R * 128);
-        ws.z_c6 = c.take<float>(R * 256);
+        ws.z_c6 = nullptr;
     } else {
         // eval: four rotating buffers; the 256-channel layers are never stored
         float *a = c.take<float>(R * 64), *b = c.take<float>(R * 128), *cc = c.take<float>(R * 64), *d = c.take<float>(R * 128);
@@ -84,6 +85,9 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.arg_t = c.take<int>(Q * 256);
     ws.arg_f = c.take<int>(Q * 256);
     ws.arg_c = c.take<int>(Q * 256);
+    ws.zext_t = c.take<float>(Q * 256);
+    ws.zext_f = c.take<float>(Q * 256);
+    ws.zext_c = c.take<float>(Q * 256);
     ws.fc_off = c.take<int>((size_t)s.n_slots + 1);
     const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
     ws.part_sum = c.take<float>(np);
@@ -177,14 +181,14 @@ struct EncRun {
         f.stat_mean = ws.bn[bn].smean; f.stat_uvar = ws.bn[bn].suvar;
         return bn_finalize(f, st);
     }
-    int pool(int bn, float *pooled, int *arg, bool slot_major) const
+    int pool(int bn, float *pooled, int *arg, float *zext, bool slot_major) const
     {
         PoolFinalize p;
         p.part_max = ws.part_max; p.part_min = ws.part_min; p.part_amax = ws.part_amax; p.part_amin = ws.part_amin;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
         p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
         p.out_slot_major = (slot_major && s.train) ? 1 : 0;
-        p.pooled = pooled; p.arg = arg;
+        p.pooled = pooled; p.arg = arg; p.zext = zext;
         return pool_finalize(p, st);
     }
 };
@@ -197,7 +201,7 @@ struct EncRun {
 
 // one T-Net: conv stack on `A0` ([R, 64] pre-BN with prologue pro0, or the K=3 input layer), FC head -> T [Q, k*k]
 int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0, bool input_k3, float *z1, float *z2, float *z3,
-             float *pooled, int *arg, float *zf1, float *zf2, float *T, int k)
+             float *pooled, int *arg, float *zext, float *zf1, float *zf2, float *T, int k)
 {
     const bool tr = e.s.train;
     if (input_k3) {
@@ -214,7 +218,7 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
     TRY(e.finalize(bn0 + 1, false));
     TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true), e.st));
     TRY(e.finalize(bn0 + 2, false));
-    TRY(e.pool(bn0 + 2, pooled, arg, true));
+    TRY(e.pool(bn0 + 2, pooled, arg, zext, true));
     // FC head on [Q, 256]
     TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, tr), e.st));
     TRY(e.finalize(bn0 + 3, true));
@@ -266,7 +270,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     }
 
     // input T-Net on xyz
-    TRY(run_tnet(e, EP_IT, BN_T1, x, -1, true, e.ws.z_t1, e.ws.z_t2, e.ws.z_t3, e.ws.pool_t, e.ws.arg_t, e.ws.z_tf1, e.ws.z_tf2, e.ws.T3, 3));
+    TRY(run_tnet(e, EP_IT, BN_T1, x, -1, true, e.ws.z_t1, e.ws.z_t2, e.ws.z_t3, e.ws.pool_t, e.ws.arg_t, e.ws.zext_t, e.ws.z_tf1, e.ws.z_tf2, e.ws.T3, 3));
     // conv_1 on cat(xyz * T3, x), conv_2
     {
         PwInput in;
@@ -280,7 +284,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(pw_gemm(e.point_layer(e.ws.z_c1, 64, e.P[EP_CONV2], 64, BN_C1, e.ws.z_c2, tr, false), e.st));
     TRY(e.finalize(BN_C2, false));
     // feature T-Net on relu(bn_2(z_c2))
-    TRY(run_tnet(e, EP_FT, BN_F1, e.ws.z_c2, BN_C2, false, e.ws.z_f1, e.ws.z_f2, e.ws.z_f3, e.ws.pool_f, e.ws.arg_f, e.ws.z_ff1, e.ws.z_ff2, feat_T, 64));
+    TRY(run_tnet(e, EP_FT, BN_F1, e.ws.z_c2, BN_C2, false, e.ws.z_f1, e.ws.z_f2, e.ws.z_f3, e.ws.pool_f, e.ws.arg_f, e.ws.zext_f, e.ws.z_ff1, e.ws.z_ff2, feat_T, 64));
     // local = relu(bn_2(z_c2)) x T64[window]  (torch.bmm, pointnetAtt.py:96)
     {
         PwGemm g = e.point_layer(e.ws.z_c2, 64, feat_T, 64, BN_C2, local, false, false);
@@ -296,7 +300,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(e.finalize(BN_C5, false));
     TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true), e.st));
     TRY(e.finalize(BN_C6, false));
-    TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, false));
+    TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, e.ws.zext_c, false));
 
     if (tr) {
         BnRunItem items[BN_ENC_COUNT];

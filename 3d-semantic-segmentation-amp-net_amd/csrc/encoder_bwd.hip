@@ -23,6 +23,8 @@ struct EncBwdWs {
     float *a1, *a2, *da2, *g2, *da1, *g1, *d_pool;   // FC: [Q,256] [Q,128] [Q,128] [Q,128] [Q,256] [Q,256] [Q,256]
     float *dT64, *dT64t;       // [Q, 4096]
     float *dWeff, *dT3;        // [Q, 576], [Q, 12]
+    float *srows, *Gm, *c0, *gram, *asum;   // [Q*256,128] [S,128,128] [S,128] [S,128,128] [S,128]: pooled-layer algebra
+    int *srow_row, *srow_cnt;  // [Q*256], [Q]
     BnBwdSlot bn[BN_ENC_COUNT];
     size_t bytes;
 };
@@ -67,6 +69,13 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.dT64t = c.take<float>(Q * 4096);
     w.dWeff = c.take<float>(Q * 576);
     w.dT3 = c.take<float>(Q * 12);
+    w.srows = c.take<float>(Q * 256 * 128);
+    w.Gm = c.take<float>((size_t)s.n_slots * 128 * 128);
+    w.c0 = c.take<float>((size_t)s.n_slots * 128);
+    w.gram = c.take<float>((size_t)s.n_slots * 128 * 128);
+    w.asum = c.take<float>((size_t)s.n_slots * 128);
+    w.srow_row = c.take<int>(Q * 256);
+    w.srow_cnt = c.take<int>(Q);
     for (int i = 0; i < BN_ENC_COUNT; ++i) {
         const size_t n = (size_t)s.n_slots * kBnC2[i];
         w.bn[i].P1 = c.take<float>(n);
@@ -146,14 +155,65 @@ struct EncBwd {
         }
         return AMPNET_OK;
     }
-    int pool(const float *d_pooled, int slot_major, const int *arg, const float *z, int bn) const
+    // Backward of a 128 -> 256 layer followed by BatchNorm + ReLU + MaxPool, WITHOUT its [rows, 256] output.
+    // With z = W a, dz = P1 dy + P2 z + P3 and dy non-zero only on the argmax rows (kernels.h, "backward of a max-pooled
+    // layer"): the data gradient is a 128 -> 128 GEMM with per-slot weights G = W^T diag(P2) W plus c0 = P3 W plus a few
+    // scattered rows, the weight gradient needs only the per-slot Gram matrix of the 128-channel input.
+    int pooled_layer(const float *d_pooled, int slot_major, const int *arg, const float *zext, int bn, const float *W, float *dW,
+                     const float *z_prev, int prev_bn, float *dy_out) const
     {
         PoolBwd p;
-        p.d_pooled = d_pooled; p.slot_major = slot_major; p.arg = arg; p.z = z;
+        p.d_pooled = d_pooled; p.slot_major = slot_major; p.arg = arg; p.zext = zext;
         p.scale = f.bn[bn].scale; p.shift = f.bn[bn].shift; p.mean = f.bn[bn].mean; p.invstd = f.bn[bn].invstd;
         p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.C = 256;
         p.dpm = b.dpm; p.P1 = b.bn[bn].P1; p.P2 = b.bn[bn].P2; p.P3 = b.bn[bn].P3; p.slot_ab = b.bn[bn].slot_ab;
-        return pool_bwd(p, st);
+        TRY(pool_bwd(p, st));
+        SparseRows sr;
+        sr.arg = arg; sr.dpm = b.dpm; sr.slot_major = slot_major; sr.P1 = b.bn[bn].P1; sr.W = W;
+        sr.Q = s.Q; sr.n_slots = s.n_slots; sr.srows = b.srows; sr.srow_row = b.srow_row; sr.srow_cnt = b.srow_cnt;
+        TRY(sparse_rows(sr, st));
+        TRY(slot_mats(W, b.bn[bn].P2, b.bn[bn].P3, s.n_slots, 256, 128, b.Gm, b.c0, st));
+        // Gram and column sums of a = relu(bn_prev(z_prev)) per slot, then dW
+        {
+            PwWgrad w;
+            w.x.z = z_prev; w.x.C = 128; w.x.act = 1; w.x.P2 = f.bn[prev_bn].scale; w.x.P3 = f.bn[prev_bn].shift;
+            w.y = act(z_prev, prev_bn, 128);
+            w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
+            w.win_off = win_off; w.Q = s.Q; w.n_slots = s.n_slots; w.rows_hint = s.R;
+            w.chunk_rows = WG_CHUNK_ROWS; w.chunks = wg_chunks(s);
+            TRY(pw_wgrad(w, st));
+            TRY(reduce_slots(b.wpart, s.Q, w.chunks, s.n_slots, 128 * 128, b.gram, st));
+            TRY(reduce_slots(b.dbpart, s.Q, w.chunks, s.n_slots, 128, b.asum, st));
+            PooledWgrad pw;
+            pw.W = W; pw.P1 = b.bn[bn].P1; pw.P2 = b.bn[bn].P2; pw.P3 = b.bn[bn].P3; pw.gram = b.gram; pw.asum = b.asum;
+            pw.arg = arg; pw.dpm = b.dpm; pw.slot_major = slot_major;
+            pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift;
+            pw.Q = s.Q; pw.n_slots = s.n_slots; pw.dW = dW;
+            TRY(pooled_wgrad(pw, st));
+        }
+        // data gradient: dy_prev = (a G[slot] + c0[slot] + scattered rows) masked by the previous layer's ReLU
+        PwDgrad d;
+        d.g.z = z_prev; d.g.C = 128; d.g.act = 1; d.g.P2 = f.bn[prev_bn].scale; d.g.P3 = f.bn[prev_bn].shift;
+        d.W = b.Gm; d.ldw = 128; d.w_slot_stride = 128 * 128; d.bias_slot = b.c0;
+        d.prev = act(z_prev, prev_bn, 128);
+        d.prev_mean = f.bn[prev_bn].mean; d.prev_invstd = f.bn[prev_bn].invstd;
+        d.part_a = f.part_sum; d.part_b = f.part_sq; d.part_chunks = s.chunks + 1;
+        d.out = dy_out; d.cp = 128;
+        d.win_off = win_off; d.Q = s.Q; d.n_slots = s.n_slots; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = s.R;
+        TRY(pw_dgrad(d, st));
+        // the scattered rows: added after the dense part, with their share of the BatchNorm-backward sums in an extra slot
+        SparseFix sf;
+        sf.srows = b.srows; sf.srow_row = b.srow_row; sf.srow_cnt = b.srow_cnt; sf.z_prev = z_prev;
+        sf.s_prev = f.bn[prev_bn].scale; sf.t_prev = f.bn[prev_bn].shift; sf.mean_prev = f.bn[prev_bn].mean; sf.invstd_prev = f.bn[prev_bn].invstd;
+        sf.Q = s.Q; sf.n_slots = s.n_slots; sf.out = dy_out; sf.part_a = f.part_sum; sf.part_b = f.part_sq;
+        sf.part_chunks = s.chunks + 1; sf.slot_idx = s.chunks;
+        TRY(sparse_fix(sf, st));
+        BnBwdFinalize fz;
+        fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
+        fz.Q = s.Q; fz.chunks = s.chunks + 1; fz.n_slots = s.n_slots; fz.C = 128;
+        fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
+        fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
+        return bn_bwd_finalize(fz, st);
     }
 
     // T-Net FC head backward: g3 [Q, kk] (slot-major rows) -> parameter grads, d_pool [Q, 256]
@@ -226,12 +286,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     hipStream_t st = e.st;
 
     // ---- conv_6 .. conv_3 --------------------------------------------------------------------------
-    TRY(e.pool(d_global, 0, f.arg_c, f.z_c6, BN_C6));
-    {
-        const GradSrc g6 = e.sparse(f.arg_c, b.dpm, 0, f.z_c6, BN_C6);
-        TRY(e.wgrad(g6, e.act(f.z_c5, BN_C5, 128), G[EP_CONV6]));
-        TRY(e.dgrad(g6, P[EP_CONV6], 128, f.z_c5, BN_C5, 128, nullptr, b.dyA));
-    }
+    TRY(e.pooled_layer(d_global, 0, f.arg_c, f.zext_c, BN_C6, P[EP_CONV6], G[EP_CONV6], f.z_c5, BN_C5, b.dyA));
     {
         const GradSrc g5 = e.dense(b.dyA, f.z_c5, BN_C5, 128);
         TRY(e.wgrad(g5, e.act(f.z_c4, BN_C4, 128), G[EP_CONV5]));
@@ -270,12 +325,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     // ---- feature T-Net ---------------------------------------------------------------------------------------
     TRY(e.tnet_fc_bwd(EP_FT, BN_F1, b.dT64, 4096, f.pool_f, f.z_ff1, f.z_ff2));
-    TRY(e.pool(b.d_pool, 1, f.arg_f, f.z_f3, BN_F3));
-    {
-        const GradSrc g = e.sparse(f.arg_f, b.dpm, 1, f.z_f3, BN_F3);
-        TRY(e.wgrad(g, e.act(f.z_f2, BN_F2, 128), G[EP_FT + TP_CONV3]));
-        TRY(e.dgrad(g, P[EP_FT + TP_CONV3], 128, f.z_f2, BN_F2, 128, nullptr, b.dyA));
-    }
+    TRY(e.pooled_layer(b.d_pool, 1, f.arg_f, f.zext_f, BN_F3, P[EP_FT + TP_CONV3], G[EP_FT + TP_CONV3], f.z_f2, BN_F2, b.dyA));
     {
         const GradSrc g = e.dense(b.dyA, f.z_f2, BN_F2, 128);
         TRY(e.wgrad(g, e.act(f.z_f1, BN_F1, 64), G[EP_FT + TP_CONV2]));
@@ -302,12 +352,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     // ---- input T-Net ----------------------------------------------------------------------------------------------
     TRY(e.tnet_fc_bwd(EP_IT, BN_T1, b.dT3, 9, f.pool_t, f.z_tf1, f.z_tf2));
-    TRY(e.pool(b.d_pool, 1, f.arg_t, f.z_t3, BN_T3));
-    {
-        const GradSrc g = e.sparse(f.arg_t, b.dpm, 1, f.z_t3, BN_T3);
-        TRY(e.wgrad(g, e.act(f.z_t2, BN_T2, 128), G[EP_IT + TP_CONV3]));
-        TRY(e.dgrad(g, P[EP_IT + TP_CONV3], 128, f.z_t2, BN_T2, 128, nullptr, b.dyA));
-    }
+    TRY(e.pooled_layer(b.d_pool, 1, f.arg_t, f.zext_t, BN_T3, P[EP_IT + TP_CONV3], G[EP_IT + TP_CONV3], f.z_t2, BN_T2, b.dyA));
     {
         const GradSrc g = e.dense(b.dyA, f.z_t2, BN_T2, 128);
         TRY(e.wgrad(g, e.act(f.z_t1, BN_T1, 64), G[EP_IT + TP_CONV2]));

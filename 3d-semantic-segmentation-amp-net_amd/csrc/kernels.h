@@ -104,6 +104,7 @@ struct PoolFinalize {
     int out_slot_major = 0;       // orow(q) = (q % n_slots) * (Q / n_slots) + q / n_slots, else q
     float *pooled = nullptr;      // [Q, C]
     int *arg = nullptr;           // [Q, C] or nullptr
+    float *zext = nullptr;        // [Q, C] or nullptr: the pre-BatchNorm extreme itself (row q)
 };
 int pool_finalize(const PoolFinalize &a, hipStream_t st);
 
@@ -147,6 +148,7 @@ struct GradSrc {
     const float *dpool = nullptr;  // [Q, C]
     int dpool_slot_major = 0;
     const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, C]
+    int act = 0;                   // 1: g = relu(z * P2 + P3) -- a recomputed forward activation used as the operand
     int C = 0;
 };
 
@@ -167,12 +169,17 @@ struct PwDgrad {
     int ldw = 0;
     long w_win_stride = 0;         // != 0: per-window matrix T[pidx][j][k] (the bmm transform), rows j, k contiguous
     int perwin_slot_major = 0;
+    long w_slot_stride = 0;        // != 0: shared-layout weights per SLOT at W + slot * w_slot_stride
+    const float *bias_slot = nullptr;   // [n_slots, cp] added to every row of the slot
+    const int *rowmap = nullptr;   // [rows]: -1 or an index into srows whose row is added (sparse max-pool part)
+    const float *srows = nullptr;  // [*, cp]
     const float *add = nullptr;    // [rows, cp] or nullptr
     ActSrc prev;                   // prev.z == nullptr: raw output, no mask, no partial sums
     const float *prev_mean = nullptr, *prev_invstd = nullptr;   // [n_slots, cp]
     float *out = nullptr;          // [rows, cp]
     int cp = 0;                    // output columns (<= 128 per launch block, any multiple of 32 up to 256)
-    float *part_a = nullptr, *part_b = nullptr;   // [Q * chunks, cp]: sum dy, sum dy * zhat of layer l-1
+    float *part_a = nullptr, *part_b = nullptr;   // [Q * part_chunks, cp]: sum dy, sum dy * zhat of layer l-1
+    int part_chunks = 0;           // partial slots per window (0 = chunks); > chunks leaves room for sparse_fix's slot
     const int *win_off = nullptr;
     int Q = 0, n_slots = 1, chunk_rows = 512, chunks = 1;
     long rows_hint = 0;
@@ -224,7 +231,7 @@ struct PoolBwd {
     const float *d_pooled = nullptr;   // [Q, C] grad wrt pooled (post-ReLU) activations, row = prow(q)
     int slot_major = 0;
     const int *arg = nullptr;          // [Q, C]
-    const float *z = nullptr;          // [rows, C] pre-BN output of the pooled layer
+    const float *zext = nullptr;       // [Q, C] pre-BN value of the pooled layer at its argmax row (pool_finalize)
     const float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;   // [n_slots, C]
     const int *win_off = nullptr;
     int Q = 0, n_slots = 1, C = 256;
@@ -232,6 +239,49 @@ struct PoolBwd {
     float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr, *slot_ab = nullptr;
 };
 int pool_bwd(const PoolBwd &a, hipStream_t st);
+
+// ---- backward of a max-pooled layer without its [rows, 256] output ------------------------------------------------
+// With z = W a, dz = P1 dy + P2 z + P3 and dy non-zero only on the argmax rows:
+//   dgrad:  dz W = a G + c0 + S,   G = W^T diag(P2) W (per slot),  c0 = P3 W,  S = rows scattered from (P1 dy) W
+//   wgrad:  dz^T a = diag(P2) W Gram + P3 (x) asum + sparse,   Gram = a^T a, asum = sum a (per slot)
+struct SparseRows {        // S rows of one layer: srows[q * C + i][:] and rowmap[row] = q * C + i
+    const int *arg = nullptr;           // [Q, C]
+    const float *dpm = nullptr;         // [Q, C] masked pooled gradient (row prow(q))
+    int slot_major = 0;
+    const float *P1 = nullptr;          // [n_slots, C]
+    const float *W = nullptr;           // [C, cp]
+    int Q = 0, n_slots = 1, C = 256, cp = 128;
+    float *srows = nullptr;             // [Q * C, cp] merged rows of window q at [q * C + i], i < srow_cnt[q]
+    int *srow_row = nullptr;            // [Q * C] the row each merged row belongs to
+    int *srow_cnt = nullptr;            // [Q]
+};
+int sparse_rows(const SparseRows &a, hipStream_t st);
+// adds the merged sparse rows into the masked data gradient and writes their share of the BatchNorm-backward sums
+// into partial slot `slot_idx` of every window:  out[row] += mask * S;  part[(q * part_chunks + slot_idx)] = sums
+struct SparseFix {
+    const float *srows = nullptr;
+    const int *srow_row = nullptr, *srow_cnt = nullptr;
+    const float *z_prev = nullptr, *s_prev = nullptr, *t_prev = nullptr, *mean_prev = nullptr, *invstd_prev = nullptr;
+    int Q = 0, n_slots = 1, C = 256, cp = 128;
+    float *out = nullptr;               // [rows, cp]
+    float *part_a = nullptr, *part_b = nullptr;
+    int part_chunks = 1, slot_idx = 0;
+};
+int sparse_fix(const SparseFix &a, hipStream_t st);
+// G[s][j][k] = sum_c W[c][j] P2[s][c] W[c][k];  c0[s][k] = sum_c P3[s][c] W[c][k]
+int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st);
+// out[s][e] = sum over windows q = s (mod n_slots), chunks: part[(q * chunks + ch) * n_el + e]
+int reduce_slots(const float *part, int Q, int chunks, int n_slots, int n_el, float *out, hipStream_t st);
+struct PooledWgrad {
+    const float *W = nullptr, *P2 = nullptr, *P3 = nullptr, *gram = nullptr, *asum = nullptr;   // [C,cp] [S,C] [S,C] [S,cp,cp] [S,cp]
+    const int *arg = nullptr;           // [Q, C]
+    const float *dpm = nullptr, *P1 = nullptr;
+    int slot_major = 0;
+    const float *z_prev = nullptr, *s_prev = nullptr, *t_prev = nullptr;   // [rows, cp], [S, cp]
+    int Q = 0, n_slots = 1, C = 256, cp = 128;
+    float *dW = nullptr;                // [C, cp]
+};
+int pooled_wgrad(const PooledWgrad &a, hipStream_t st);
 
 // C[M, N] = op(A) * op(B) (+ C if accumulate); row-major, small problems (T-Net FC layers, attention projections)
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,

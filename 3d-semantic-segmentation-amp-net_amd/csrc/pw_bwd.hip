@@ -31,7 +31,7 @@ __device__ __forceinline__ int pidx_of_b(int q, int n_slots, int Q, int slot_maj
 // ----------------------------------------------------------------------------------------------------
 // pw_dgrad
 // ----------------------------------------------------------------------------------------------------
-template <int K, int NT, int NW>
+template <int K, int NT, int NW, bool EXTRA>
 __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
 {
     constexpr int CB = 32 * NT;
@@ -50,18 +50,20 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
     const int nrows = max(row_end - row_begin, 0);
     const int slot = (a.n_slots > 1) ? (q % a.n_slots) : 0;
     const int pidx = pidx_of_b(q, a.n_slots, a.Q, a.perwin_slot_major);
-    const bool sparse = a.g.dy == nullptr;
-    const bool has_bn = a.g.P1 != nullptr;
+    const bool act = a.g.act != 0;                       // operand = relu(z * P2 + P3)
+    const bool sparse = a.g.dy == nullptr && !act;
+    const bool has_bn = a.g.P1 != nullptr || act;        // z is loaded
 
     if (nrows > 0) {
         if (a.w_win_stride == 0) {
+            const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
             // shared weight W[k][j] (torch [cout_l = K][cin_l]): transpose while staging
             // consecutive lanes take consecutive k: the LDS writes are conflict-free, the 16-byte global reads are
             // strided but L2-resident (the whole weight is <= 128 KB and every workgroup reads it)
             for (int e = tid; e < K * (CB / 4); e += NW * 64) {
                 const int k = e % K, j4 = e / K;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cb0 + 4 * j4 < a.cp) v = *reinterpret_cast<const f32x4 *>(a.W + (size_t)k * a.ldw + cb0 + 4 * j4);
+                if (cb0 + 4 * j4 < a.cp) v = *reinterpret_cast<const f32x4 *>(Wsh + (size_t)k * a.ldw + cb0 + 4 * j4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sW[(4 * j4 + i) * LDW + k] = v[i];
             }
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             }
         }
         for (int e = tid; e < K; e += NW * 64) {
-            sP[e] = has_bn ? a.g.P1[(size_t)slot * K + e] : 1.0f;
+            sP[e] = a.g.P1 ? a.g.P1[(size_t)slot * K + e] : 1.0f;
             sP[K + e] = has_bn ? a.g.P2[(size_t)slot * K + e] : 0.0f;
             sP[2 * K + e] = has_bn ? a.g.P3[(size_t)slot * K + e] : 0.0f;
             if (sparse) {
@@ -93,10 +95,11 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
     const float dscale = has_drop ? 1.0f / (1.0f - a.prev.drop_p) : 1.0f;
     const bool do_part = a.part_a != nullptr;
 
-    float c_s[NT], c_t[NT], c_m[NT], c_i[NT], s_a[NT], s_b[NT];
+    float c_s[NT], c_t[NT], c_m[NT], c_i[NT], c_b[NT], s_a[NT], s_b[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = cb0 + 32 * t + r;
+        c_b[t] = (a.bias_slot && col < a.cp) ? a.bias_slot[(size_t)slot * a.cp + col] : 0.f;
         const bool ok = has_prev && col < a.cp && a.prev.s != nullptr;
         c_s[t] = ok ? a.prev.s[(size_t)slot * a.cp + col] : 1.0f;
         c_t[t] = ok ? a.prev.t[(size_t)slot * a.cp + col] : 0.0f;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
         const size_t o = (size_t)arow_of(tile) * K + 32 * kb + 4 * h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (!sparse) dy[j] = *reinterpret_cast<const f32x4 *>(a.g.dy + o + 8 * j);
+            if (!sparse && !act) dy[j] = *reinterpret_cast<const f32x4 *>(a.g.dy + o + 8 * j);
             if (has_bn) z[j] = *reinterpret_cast<const f32x4 *>(a.g.z + o + 8 * j);
         }
     };
@@ -153,11 +156,16 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
                     const f32x4 dp = *reinterpret_cast<const f32x4 *>(sDp + k0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dyv[i] = (ar[i] == arow && r < valid) ? dp[i] : 0.f;
-                } else {
+                } else if (!act) {
                     dyv = dy_cur[j];
                 }
                 f32x4 gv;
-                if (has_bn) {
+                if (act) {
+                    const f32x4 p2 = *reinterpret_cast<const f32x4 *>(sP + K + k0);
+                    const f32x4 p3 = *reinterpret_cast<const f32x4 *>(sP + 2 * K + k0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[i] = fmaxf(fmaf(z_cur[j][i], p2[i], p3[i]), 0.f);
+                } else if (has_bn) {
                     const f32x4 p1 = *reinterpret_cast<const f32x4 *>(sP + k0);
                     const f32x4 p2 = *reinterpret_cast<const f32x4 *>(sP + K + k0);
                     const f32x4 p3 = *reinterpret_cast<const f32x4 *>(sP + 2 * K + k0);
@@ -181,21 +189,43 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             }
         }
 
-        // ---- epilogue: lane = column of layer l-1, registers = rows ----
+        // ---- epilogue: lane = column of layer l-1, registers = rows.  All global loads of a 32 x 32 sub-tile are
+        // issued back to back BEFORE anything consumes them (a load-use-load-use chain costs one memory round trip
+        // per element: 64 per tile, ten times the tile's MFMA time).
+        int rmap[16];
+        if (EXTRA && a.rowmap) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                rmap[e] = rr < valid ? a.rowmap[row0 + rr] : -1;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = cb0 + 32 * t + r;
             const bool cok = col < a.cp;
+            const int ccol = cok ? col : 0;
+            float zv[16], xv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const size_t o = (size_t)(row0 + min(rr, valid - 1)) * a.cp + ccol;      // clamped: always a valid address
+                zv[e] = has_prev ? a.prev.z[o] : 0.f;
+                if (EXTRA) {
+                    float x = a.add ? a.add[o] : 0.f;
+                    if (a.rowmap && rmap[e] >= 0) x += a.srows[(size_t)rmap[e] * a.cp + ccol];
+                    xv[e] = x;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (!(rr < valid && cok)) continue;
                 const size_t o = (size_t)(row0 + rr) * a.cp + col;
-                float v = acc[t][e];
-                if (a.add) v += a.add[o];
+                float v = acc[t][e] + c_b[t];
+                if (EXTRA) v += xv[e];
                 if (has_prev) {
-                    const float zv = a.prev.z[o];
-                    bool keep = fmaf(zv, c_s[t], c_t[t]) > 0.f;
+                    bool keep = fmaf(zv[e], c_s[t], c_t[t]) > 0.f;
                     if (a.prev.s == nullptr) keep = true;            // identity activation: no mask
                     if (has_drop) {
                         const bool dk = mix32(((uint32_t)(row0 + rr) * (uint32_t)a.cp + (uint32_t)col) ^ a.prev.drop_seed) >= dthr;
@@ -204,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
                     v = keep ? v : 0.f;
                     if (do_part) {
                         s_a[t] += v;
-                        s_b[t] = fmaf(v, (zv - c_m[t]) * c_i[t], s_b[t]);
+                        s_b[t] = fmaf(v, (zv[e] - c_m[t]) * c_i[t], s_b[t]);
                     }
                 }
                 a.out[o] = v;
@@ -233,21 +263,21 @@ __global__ __launch_bounds__(NW * 64, 2) void pw_dgrad_kernel(PwDgrad a)
             sa += red[(w * CB + c) * 2 + 0];
             sb += red[(w * CB + c) * 2 + 1];
         }
-        const size_t o = (size_t)(q * a.chunks + chunk) * a.cp + col;
+        const size_t o = (size_t)(q * (a.part_chunks ? a.part_chunks : a.chunks) + chunk) * a.cp + col;
         a.part_a[o] = sa;
         a.part_b[o] = sb;
     }
 }
 
-template <int K, int NT, int NW>
-static int launch_dgrad(const PwDgrad &a, hipStream_t st)
+template <int K, int NT, int NW, bool EXTRA>
+static int launch_dgrad_x(const PwDgrad &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = (size_t)(CB * (K + 4) + 5 * K) * sizeof(float);
     constexpr size_t lds_red = (size_t)NW * CB * 2 * sizeof(float);
     constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
     static bool attr_set = false;
-    auto kern = pw_dgrad_kernel<K, NT, NW>;
+    auto kern = pw_dgrad_kernel<K, NT, NW, EXTRA>;
     if (!attr_set) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -256,18 +286,25 @@ static int launch_dgrad(const PwDgrad &a, hipStream_t st)
         attr_set = true;
     }
     char name[64];
-    snprintf(name, sizeof(name), "pw_dgrad<%d,%d>%s", K, CB, a.g.dy ? "" : "+sparse");
+    snprintf(name, sizeof(name), "pw_dgrad<%d,%d>%s", K, CB, a.g.act ? "+act" : (a.g.dy ? "" : "+sparse"));
     const double rows = (double)a.rows_hint;
     ProfScope prof(name, 2.0 * rows * K * a.cp, rows * 4.0 * ((a.g.dy ? K : 0) + (a.g.P1 ? K : 0) + (a.prev.z ? 2.0 : 1.0) * a.cp), st);
     hipLaunchKernelGGL(kern, dim3(a.chunks, a.Q, cdiv(a.cp, CB)), dim3(NW * 64), lds, st, a);
     return check_launch("pw_dgrad_kernel");
 }
 
+template <int K, int NT, int NW>
+static int launch_dgrad(const PwDgrad &a, hipStream_t st)
+{
+    return (a.add || a.rowmap) ? launch_dgrad_x<K, NT, NW, true>(a, st) : launch_dgrad_x<K, NT, NW, false>(a, st);
+}
+
 int pw_dgrad(const PwDgrad &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.W && a.out && a.win_off, "pw_dgrad: null pointer");
-    AMPNET_REQUIRE(a.g.dy || (a.g.arg && a.g.dpool), "pw_dgrad: neither dense nor sparse gradient source");
-    AMPNET_REQUIRE(!a.g.P1 || (a.g.P2 && a.g.P3 && a.g.z), "pw_dgrad: BatchNorm constants incomplete");
+    AMPNET_REQUIRE(a.g.dy || a.g.act || (a.g.arg && a.g.dpool), "pw_dgrad: neither dense nor sparse gradient source");
+    AMPNET_REQUIRE(!(a.g.P1 || a.g.act) || (a.g.P2 && a.g.P3 && a.g.z), "pw_dgrad: BatchNorm constants incomplete");
+    AMPNET_REQUIRE(!a.rowmap || a.srows, "pw_dgrad: rowmap without srows");
     AMPNET_REQUIRE(a.cp >= 1 && a.cp % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_dgrad: cp / ldw must be multiples of 4");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.z), "pw_dgrad: partial sums need the previous layer");
     const int nt = a.cp > 64 ? 4 : (a.cp > 32 ? 2 : 1);
@@ -310,8 +347,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
     const int row_end = min(a.win_off[q + 1], row_begin + a.chunk_rows);
     const int slot = (a.n_slots > 1) ? (q % a.n_slots) : 0;
     const int CX = a.x.C, CY = a.y.C;
-    const bool sparse = a.x.dy == nullptr;
-    const bool has_bn = a.x.P1 != nullptr;
+    const bool x_act = a.x.act != 0;
+    const bool sparse = a.x.dy == nullptr && !x_act;
+    const bool has_bn = a.x.P1 != nullptr && !x_act;
     const bool y_act = a.y.s != nullptr;
     const bool y_drop = a.y.drop_p > 0.f;
     const uint32_t dthr = drop_threshold(a.y.drop_p);
@@ -324,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f}, ys = p1, yt = p2, dp = p2;
     i32x4 ar = {-1, -1, -1, -1};
     if (xok) {
-        if (has_bn) {
-            p1 = *reinterpret_cast<const f32x4 *>(a.x.P1 + (size_t)slot * CX + xc);
+        if (has_bn) p1 = *reinterpret_cast<const f32x4 *>(a.x.P1 + (size_t)slot * CX + xc);
+        if (has_bn || x_act) {
             p2 = *reinterpret_cast<const f32x4 *>(a.x.P2 + (size_t)slot * CX + xc);
             p3 = *reinterpret_cast<const f32x4 *>(a.x.P3 + (size_t)slot * CX + xc);
         }
@@ -347,8 +385,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
             const int row = blk_row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < row_end ? row : row_begin);
             if (xok) {
-                if (!sparse) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.x.dy + rr * CX + xc);
-                if (has_bn) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.x.z + rr * CX + xc);
+                if (!sparse && !x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.x.dy + rr * CX + xc);
+                if (has_bn || x_act) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.x.z + rr * CX + xc);
             }
         }
 #pragma unroll
@@ -365,14 +403,17 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
             const int row = blk_row0 + rsx + SX * i;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
             if (row < row_end && xok) {
-                f32x4 dyv;
+                f32x4 dyv = {0.f, 0.f, 0.f, 0.f};
                 if (sparse) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dyv[c] = (ar[c] == row) ? dp[c] : 0.f;
-                } else {
+                } else if (!x_act) {
                     dyv = rx_dy[i];
                 }
-                if (has_bn) {
+                if (x_act) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaxf(fmaf(rx_z[i][c], p2[c], p3[c]), 0.f);
+                } else if (has_bn) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) xv[c] = fmaf(dyv[c], p1[c], fmaf(rx_z[i][c], p2[c], p3[c]));
                 } else {
@@ -468,12 +509,12 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(PwWgrad a)
 int pw_wgrad(const PwWgrad &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.dWpart && a.win_off && a.y.z, "pw_wgrad: null pointer");
-    AMPNET_REQUIRE(a.x.dy || (a.x.arg && a.x.dpool), "pw_wgrad: neither dense nor sparse gradient source");
-    AMPNET_REQUIRE(!a.x.P1 || (a.x.P2 && a.x.P3 && a.x.z), "pw_wgrad: BatchNorm constants incomplete");
+    AMPNET_REQUIRE(a.x.dy || a.x.act || (a.x.arg && a.x.dpool), "pw_wgrad: neither dense nor sparse gradient source");
+    AMPNET_REQUIRE(!(a.x.P1 || a.x.act) || (a.x.P2 && a.x.P3 && a.x.z), "pw_wgrad: BatchNorm constants incomplete");
     AMPNET_REQUIRE(a.x.C % 4 == 0 && a.y.C % 4 == 0 && a.ldp >= a.y.C, "pw_wgrad: channel counts must be multiples of 4");
     AMPNET_REQUIRE(a.chunks >= 1 && a.chunk_rows % 64 == 0, "pw_wgrad: chunk_rows must be a multiple of 64");
     char name[64];
-    snprintf(name, sizeof(name), "pw_wgrad<%d,%d>%s", a.x.C, a.y.C, a.x.dy ? "" : "+sparse");
+    snprintf(name, sizeof(name), "pw_wgrad<%d,%d>%s", a.x.C, a.y.C, a.x.act ? "+gram" : (a.x.dy ? "" : "+sparse"));
     const double rows = (double)a.rows_hint;
     const int tx = a.x.C > 64 ? 4 : 2, ty = a.y.C > 64 ? 4 : 2;
     ProfScope prof(name, 2.0 * rows * a.x.C * a.y.C,

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
         }
         a.pooled[(size_t)orow * a.C + c] = fmaxf(fmaf(best, sc, sh), 0.f);
         if (a.arg) a.arg[(size_t)q * a.C + c] = arg;
+        if (a.zext) a.zext[(size_t)q * a.C + c] = best;
     }
 }
 

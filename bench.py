@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--mode", choices=["fwd", "train", "auto"], default="auto")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -243,7 +244,7 @@ def main():
             "roofline": roofline_from(rows),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))
-                               for r in rows], key=lambda r: -r["ms_per_step"])[:8],
+                               for r in rows], key=lambda r: -r["ms_per_step"])[:args.kernels],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mode)
