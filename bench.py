@@ -143,12 +143,67 @@ def cpu_baseline(mode, budget_s=20.0):
                 sample=f"{n} x ({Bc} samples x {N_WIN} windows x {N_POINTS} pts) {mode}, oracle torch-CPU fp32, {dt:.1f} s")
 
 
+def bench_fps(args, dev, rank, world, dist):
+    """BASELINE.json configs[4]: farthest-point sampling, 16 clouds x 8192 points -> 4096 samples per GPU
+    (data_proc/sample_fps.py:23-31 sizes).  Clouds are independent: replicas only, no collective.
+    Roofline accounting: 16 B per (candidate, round) = 12 B xyz + 4 B running minimum."""
+    synth = sub("synthetic")
+    U = sub("utils.utils")
+    B, N, S = args.batch or 16, 8192, 4096
+    xyz = torch.from_numpy(synth.clouds(200 + rank, B, N)).to(dev)
+    for _ in range(max(args.warmup, 1)):
+        idx = U.fps_indices(xyz, S)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        idx = U.fps_indices(xyz, S)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps              # the kernel runs on torch's current stream
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        alg_bytes = float(B) * S * N * 16
+        ach = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {"metric": "FPS selections/sec (N=8192 -> 4096)", "value": round(world * B * S * args.steps / dt, 1), "unit": "selections/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"farthest-point sampling, {B} clouds x {N} points -> {S} samples per GPU", "parallelism": f"replicas{world}"},
+               "roofline": {"bound": "hbm", "kernel": "fps_kernel<1024,8>", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                            "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "launch_ms": round(kern_ms, 4),
+                            "note": "algorithmic 16 B per (candidate, round); the cloud is register-resident, true HBM traffic is B*(N*12+S*4) bytes"}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import fps_oracle
+            pc = synth.clouds(200, 1, N)[0]
+            t1 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t1 < 10.0 and n < 8:
+                fps_oracle.fps_indices_c(pc, S)
+                n += 1
+            dtc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(n * S / dtc, 1), "unit": "selections/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n} clouds x {N} -> {S}, oracle/fps_oracle.c (scalar C), {dtc:.1f} s"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["fwd", "train", "auto"], default="auto")
+    ap.add_argument("--mode", choices=["fwd", "train", "fps", "auto"], default="auto")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
@@ -165,6 +220,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "fps":
+        return bench_fps(args, dev, rank, world, dist)
 
     trainer_mod = None
     try:
@@ -226,6 +284,21 @@ def main():
     rows = profile_read()
     L.ampnet_profile_enable(0)
 
+    fwd_ms = None
+    if mode == "train":        # the metric also asks for forward ms/window: eval forward of the same batch, same modules
+        enc.eval(); att.eval()
+        for _ in range(2):
+            with torch.no_grad():
+                S.forward_batch(enc, att, x, t, centd, cw, want_loss=False, want_preds=True)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            with torch.no_grad():
+                S.forward_batch(enc, att, x, t, centd, cw, want_loss=False, want_preds=True)
+        torch.cuda.synchronize(dev)
+        fwd_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        enc.train(); att.train()
+
     if rank == 0:
         pts_step = B * N_WIN * N_POINTS
         value = world * pts_step * args.steps / dt
@@ -239,6 +312,7 @@ def main():
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "ms_per_window": round(dt / args.steps * 1e3 / (B * N_WIN), 5),
+            "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "roofline": roofline_from(rows),

@@ -170,3 +170,36 @@ def test_reference_style_loop_with_autograd(golden, synth, params):
             ps = g[f"s1_{tag}_psum/{k}"]
             np.testing.assert_allclose(p.detach().double().abs().sum().item(), ps[1], rtol=2e-4,
                                        atol=2.1e-3 * max(1.0, 0.02 * p.numel()), err_msg=k)
+
+
+def test_validation_split_miou_identical_to_oracle(synth, params):
+    """north_star: identical mIoU on a fixed synthetic validation split.  8 samples (2 batches of 4), W = 9 cluster
+    slots, N = 512: per-class IoU (utils/get_metrics.py definition), their mean and the accuracy from the HIP
+    predictions equal the oracle's on the same weights."""
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle import ampnet_oracle as O
+    from helpers import torch_params
+    S = sub("pointNet.amp_step")
+    M = sub("utils.get_metrics")
+    enc, att = _models(synth, params)
+    enc.eval(); att.eval()
+    ep = torch_params(synth.make_params(3, params.ENC_PARAMS)); eb = torch_params(synth.make_buffers(3, params.ENC_BUFFERS))
+    hp = torch_params(synth.make_params(4, params.HEAD_PARAMS)); hb = torch_params(synth.make_buffers(4, params.HEAD_BUFFERS))
+    all_hip, all_ora, all_tg = [], [], []
+    for b in range(2):
+        pc, tg, cent, _ = synth.sample_batch(700 + b, 4, 512, max_w=9)
+        x = np.ascontiguousarray(pc.transpose(0, 3, 1, 2))
+        t = np.ascontiguousarray(tg.transpose(0, 2, 1))
+        with torch.no_grad():
+            out = S.forward_batch(enc, att, x, t, cent, None, want_loss=False, want_preds=True)
+            logits, tpc, _, _ = O.forward_windows(ep, eb, hp, hb, torch.from_numpy(pc), torch.from_numpy(tg), torch.from_numpy(cent), False, False)
+        all_hip.append(out["preds"].cpu().numpy().reshape(-1))
+        all_ora.append(O.predictions(logits).numpy().reshape(-1))
+        all_tg.append(tpc.numpy().reshape(-1))
+    hip, ora, tgt = np.concatenate(all_hip), np.concatenate(all_ora), np.concatenate(all_tg)
+    keep = tgt != -1
+    assert (hip != ora).sum() <= 3                              # fp32 argmax ties only
+    iou_h = [M.get_iou_obj(hip[keep], tgt[keep], c) for c in range(5)]
+    iou_o = [O.iou_obj(ora[keep], tgt[keep], c) for c in range(5)]
+    assert np.allclose(iou_h, iou_o, atol=2e-5, equal_nan=True)
+    assert abs(np.nanmean(iou_h) - np.nanmean(iou_o)) < 1e-5
