@@ -116,7 +116,20 @@ __global__ __launch_bounds__(HO_ROWS) void head_out_kernel(HeadOut a)
         sSc[tid] = a.scale[tid];
         sSh[tid] = a.shift[tid];
     }
-    for (int e = tid; e < n * 64; e += HO_ROWS) sT[e / 64][e % 64] = a.z3[(size_t)row0 * 64 + e];
+    // tile load in batches of 8 independent loads (a load -> store -> load chain costs one memory round trip each)
+    for (int e0 = tid; e0 < n * 64; e0 += 8 * HO_ROWS) {
+        float tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * HO_ROWS;
+            tmp[u] = e < n * 64 ? a.z3[(size_t)row0 * 64 + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * HO_ROWS;
+            if (e < n * 64) sT[e / 64][e % 64] = tmp[u];
+        }
+    }
     __syncthreads();
     float wnll = 0.f, wsum = 0.f;
     if (tid < n) {

@@ -279,18 +279,35 @@ int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *
     return check_launch("fc_bn_bwd_kernel");
 }
 
-__global__ void colsum_kernel(const float *__restrict__ x, int rows, int C, float *__restrict__ out)
+// block = 32 columns x 8 row groups, fixed summation order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int rows, int C, float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * C + c];
-    out[c] = s;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int r = g;
+        for (; r + 24 < rows; r += 32) {
+            const float v0 = x[(size_t)r * C + c], v1 = x[(size_t)(r + 8) * C + c], v2 = x[(size_t)(r + 16) * C + c], v3 = x[(size_t)(r + 24) * C + c];
+            s0 += v0 + v2;
+            s1 += v1 + v3;
+        }
+        for (; r < rows; r += 8) s0 += x[(size_t)r * C + c];
+    }
+    red[g][cl] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cl];
+        out[c] = s;
+    }
 }
 
 int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, rows, C, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, x, rows, C, out);
     return check_launch("colsum_kernel");
 }
 
@@ -314,11 +331,24 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
         __syncthreads();
         for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
         __syncthreads();
-        for (int i = wave; i < n; i += 4) {
-            const size_t o = (size_t)(base + i) * 64 + lane;
-            const float g = fmaf(a.dy[o], p1, fmaf(a.z[o], p2, p3));
+        for (int i0 = wave; i0 < n; i0 += 32) {        // 8 rows per trip: 16 independent loads, then the FMAs
+            float dyv[8], zv[8];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, sx[i * 9 + f], acc[f]);
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + 4 * u, n - 1);
+                const size_t o = (size_t)(base + i) * 64 + lane;
+                dyv[u] = a.dy[o];
+                zv[u] = a.z[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 4 * u;
+                if (i < n) {
+                    const float g = fmaf(dyv[u], p1, fmaf(zv[u], p2, p3));
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, sx[i * 9 + f], acc[f]);
+                }
+            }
         }
     }
 #pragma unroll

@@ -43,17 +43,27 @@ __global__ __launch_bounds__(HB_ROWS) void head_out_bwd_kernel(HeadOutBwd a)
     __syncthreads();
     const uint32_t thr = drop_threshold(a.drop_p);
     const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    for (int e = tid; e < HB_ROWS * 64; e += HB_ROWS) {
+    for (int e0 = tid; e0 < HB_ROWS * 64; e0 += 8 * HB_ROWS) {
+      float tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {               // 8 independent loads in flight, then their uses
+          const int e = e0 + u * HB_ROWS;
+          tmp[u] = (e / 64) < n ? a.z3[(size_t)row0 * 64 + e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * HB_ROWS;
         const int i = e / 64, k = e % 64;
         float av = 0.f, zh = 0.f;
         if (i < n) {
-            const float zv = a.z3[(size_t)(row0 + i) * 64 + k];
+            const float zv = tmp[u];
             zh = (zv - sMe[k]) * sIs[k];
             av = fmaxf(fmaf(zv, sSc[k], sSh[k]), 0.f);
             if (a.drop_p > 0.f) av = (mix32(((uint32_t)(row0 + i) * 64u + (uint32_t)k) ^ a.drop_seed) >= thr) ? av * dscale : 0.f;
         }
         sA[i][k] = av;
         sZ[i][k] = zh;
+      }
     }
     {
         const int row = row0 + tid;

@@ -542,11 +542,14 @@ __global__ __launch_bounds__(256) void reduce_windows_kernel(const float *__rest
     float s0 = 0.f, s1 = 0.f;
     if (ok) {
         int qi = g;
-        for (; qi + 8 < Q; qi += 16) {
-            s0 += p[(size_t)qi * stride];
-            s1 += p[(size_t)(qi + 8) * stride];
+        for (; qi + 56 < Q; qi += 64) {             // 8 independent loads per trip
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(qi + 8 * u) * stride];
+            s0 += (v[0] + v[2]) + (v[4] + v[6]);
+            s1 += (v[1] + v[3]) + (v[5] + v[7]);
         }
-        if (qi < Q) s0 += p[(size_t)qi * stride];
+        for (; qi < Q; qi += 8) s0 += p[(size_t)qi * stride];
     }
     red[g][el] = s0 + s1;
     __syncthreads();

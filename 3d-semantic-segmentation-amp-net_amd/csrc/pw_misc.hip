@@ -45,7 +45,14 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
     for (int base = row_begin; base < row_end; base += IN_ROWS) {
         const int n = min(IN_ROWS, row_end - base);
         __syncthreads();
-        for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
+        {
+            float tmp[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) tmp[u] = (tid + 256 * u) < n * 9 ? a.x[(size_t)base * 9 + tid + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+                if ((tid + 256 * u) < n * 9) sx[tid + 256 * u] = tmp[u];
+        }
         __syncthreads();
         for (int i = wave; i < n; i += 4) {
             float z = 0.f;
