@@ -30,7 +30,9 @@ __global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinal
     rb[g][cl] = sb;
     if (threadIdx.x == 0) rows_s = 0;
     __syncthreads();
-    {
+    if (a.uniform_rows > 0) {
+        if (threadIdx.x == 0) rows_s = per_slot * a.uniform_rows;
+    } else {
         int rows = 0;
         for (int i = threadIdx.x; i < per_slot; i += 64 * BFIN_G) {
             const int q = slot + i * a.n_slots;
@@ -371,34 +373,48 @@ int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 // mode 0 (T-Net conv_1 on xyz): dW[c][f] = sum_q dWeff[q][c][f], f < 3
 // mode 1 (encoder conv_1):      dW[c][3+f] = sum_q dWeff[q][c][f];  dW[c][d] = sum_q sum_i T[p(q)][i][d] * dWeff[q][c][i];
 //                               dT[p(q)][i][d] = sum_c dWeff[q][c][i] * W[c][d]
-__global__ __launch_bounds__(64) void input_param_grads_kernel(const float *__restrict__ dWeff, const float *__restrict__ W,
-                                                              const float *__restrict__ T, int Q, int n_slots, int slot_major, int mode,
-                                                              float *__restrict__ dW, float *__restrict__ dT)
+__global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__restrict__ dWeff, const float *__restrict__ W,
+                                                               const float *__restrict__ T, int Q, int n_slots, int slot_major, int mode,
+                                                               float *__restrict__ dW, float *__restrict__ dT)
 {
-    const int c = threadIdx.x;       // channel
     if (blockIdx.x == 0) {
-        if (mode == 0) {
-            float s[3] = {0.f, 0.f, 0.f};
-            for (int q = 0; q < Q; ++q)
-                for (int f = 0; f < 3; ++f) s[f] += dWeff[((size_t)q * 64 + c) * 9 + f];
-            for (int f = 0; f < 3; ++f) dW[c * 3 + f] = s[f];
-        } else {
-            float s[12] = {};
-            for (int q = 0; q < Q; ++q) {
+        // block 0: the weight gradient, thread = (channel c, window group g); groups summed in fixed order
+        __shared__ float red[4][64][12];
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+        float s[12];
+#pragma unroll
+        for (int f = 0; f < 12; ++f) s[f] = 0.f;
+        for (int q = g; q < Q; q += 4) {
+            const float *e = dWeff + ((size_t)q * 64 + c) * 9;
+            float ev[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) ev[f] = e[f];
+            if (mode == 0) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) s[f] += ev[f];
+            } else {
                 const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
-                const float *e = dWeff + ((size_t)q * 64 + c) * 9;
-                for (int f = 0; f < 9; ++f) s[3 + f] += e[f];
-                for (int d = 0; d < 3; ++d) s[d] += T[p * 9 + 0 * 3 + d] * e[0] + T[p * 9 + 1 * 3 + d] * e[1] + T[p * 9 + 2 * 3 + d] * e[2];
+#pragma unroll
+                for (int f = 0; f < 9; ++f) s[3 + f] += ev[f];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) s[d] += T[p * 9 + 0 * 3 + d] * ev[0] + T[p * 9 + 1 * 3 + d] * ev[1] + T[p * 9 + 2 * 3 + d] * ev[2];
             }
-            for (int f = 0; f < 12; ++f) dW[c * 12 + f] = s[f];
+        }
+#pragma unroll
+        for (int f = 0; f < 12; ++f) red[g][c][f] = s[f];
+        __syncthreads();
+        if (g == 0) {
+            const int nf = mode == 0 ? 3 : 12;
+            for (int f = 0; f < nf; ++f) dW[c * nf + f] = (red[0][c][f] + red[1][c][f]) + (red[2][c][f] + red[3][c][f]);
         }
     } else if (mode == 1) {
         // blocks 1..: dT for windows, one (q, i, d) per thread
-        const int idx = (blockIdx.x - 1) * 64 + threadIdx.x;
+        const int idx = (blockIdx.x - 1) * 256 + threadIdx.x;
         if (idx >= Q * 9) return;
         const int q = idx / 9, i = (idx % 9) / 3, d = idx % 3;
         const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
         float s = 0.f;
+#pragma unroll 8
         for (int cc = 0; cc < 64; ++cc) s = fmaf(dWeff[((size_t)q * 64 + cc) * 9 + i], W[cc * 12 + d], s);
         dT[p * 9 + i * 3 + d] = s;
     }
@@ -407,8 +423,8 @@ __global__ __launch_bounds__(64) void input_param_grads_kernel(const float *__re
 int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
                       float *dT, hipStream_t st)
 {
-    const int blocks = 1 + (mode == 1 ? cdiv(Q * 9, 64) : 0);
-    hipLaunchKernelGGL(input_param_grads_kernel, dim3(blocks), dim3(64), 0, st, dWeff, W, T, Q, n_slots, slot_major, mode, dW, dT);
+    const int blocks = 1 + (mode == 1 ? cdiv(Q * 9, 256) : 0);
+    hipLaunchKernelGGL(input_param_grads_kernel, dim3(blocks), dim3(256), 0, st, dWeff, W, T, Q, n_slots, slot_major, mode, dW, dT);
     return check_launch("input_param_grads_kernel");
 }
 
@@ -451,74 +467,86 @@ namespace ampnet {
 
 // ----------------------------------------------------------------------------------------------------
 // sparse_rows: one workgroup per window.  Channels that share an argmax row are merged (in channel order, so the sums
-// are reproducible); the merged rows (P1 dy) W go to srows, rowmap points the window's rows at them.
+// are reproducible); the merged rows (P1 dy) W go to srows[q * C + i], their row numbers to srow_row.
 // ----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sparse_rows_kernel(SparseRows a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sS = smem;                                         // [C][cp]
-    int *sArg = reinterpret_cast<int *>(smem + a.C * a.cp);   // [C]
-    float *sCoef = reinterpret_cast<float *>(sArg + a.C);     // [C]
-    int *sIdx = reinterpret_cast<int *>(sCoef + a.C);         // [C] compact row of the channel
-    __shared__ int s_unique;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    __shared__ int sArg[256], sIdx[256], sDup[256];
+    __shared__ float sCoef[256];
+    __shared__ int s_wave_cnt[4], s_dup_cnt[4], s_unique, s_ndup;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
     const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
-    for (int c = tid; c < a.C; c += 256) {
-        const int r = a.arg[(size_t)q * a.C + c];
-        sArg[c] = r;
-        sCoef[c] = r >= 0 ? a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c] : 0.f;
+    const int c = tid;                                        // C <= 256 = blockDim
+    int r = -1;
+    if (c < a.C) r = a.arg[(size_t)q * a.C + c];
+    sArg[c] = r;
+    sCoef[c] = r >= 0 ? a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c] : 0.f;
+    __syncthreads();
+    // first[c] = lowest channel with the same argmax row; owners (first == c) get compact indices in channel order
+    int first = -1;
+    if (r >= 0) {
+        first = c;
+        for (int p = 0; p < c; ++p)
+            if (sArg[p] == r) {
+                first = p;
+                break;
+            }
+    }
+    const bool owner = r >= 0 && first == c, dup = r >= 0 && first != c;
+    const unsigned long long bo = __ballot(owner), bd = __ballot(dup);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+        s_wave_cnt[wv] = __popcll(bo);
+        s_dup_cnt[wv] = __popcll(bd);
     }
     __syncthreads();
-    // compact row index per channel, in channel order: first[c] = lowest channel with the same argmax row; the owners
-    // (first[c] == c) are numbered by a block-wide prefix count (ballot + popcount per wave, 4 wave totals in LDS)
-    __shared__ int s_wave_cnt[4];
-    int *sFirst = sIdx;                       // reuse: filled with `first`, then overwritten with the compact index
-    {
-        const int c = tid;                    // C <= 256 = blockDim
-        int first = -1;
-        if (c < a.C && sArg[c] >= 0) {
-            first = c;
-            for (int p = 0; p < c; ++p)
-                if (sArg[p] == sArg[c]) {
-                    first = p;
-                    break;
-                }
-        }
-        const bool owner = first == c && c < a.C;
-        const unsigned long long bal = __ballot(owner);
-        const int lane = tid & 63, wv = tid >> 6;
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave_cnt[wv] = __popcll(bal);
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += s_wave_cnt[w];
-        if (tid == 0) s_unique = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-        __syncthreads();
-        // owners publish their compact index; the others read their owner's
-        int *sOwn = reinterpret_cast<int *>(sS);          // [C] scratch (sS is zeroed afterwards)
-        if (owner) sOwn[c] = base + before;
-        __syncthreads();
-        if (c < a.C) sFirst[c] = first >= 0 ? sOwn[first] : -1;
+    int base = 0, dbase = 0;
+    for (int w = 0; w < wv; ++w) {
+        base += s_wave_cnt[w];
+        dbase += s_dup_cnt[w];
+    }
+    if (tid == 0) {
+        s_unique = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+        s_ndup = s_dup_cnt[0] + s_dup_cnt[1] + s_dup_cnt[2] + s_dup_cnt[3];
+    }
+    if (owner) sIdx[c] = base + __popcll(bo & below);
+    if (dup) sDup[dbase + __popcll(bd & below)] = c;         // the merged channels, in channel order
+    __syncthreads();
+    if (dup) sIdx[c] = sIdx[first];
+    if (owner) a.srow_row[(size_t)q * a.C + sIdx[c]] = r;
+    if (tid == 0) a.srow_cnt[q] = s_unique;
+    __syncthreads();
+    // every owner's row = coef * W[c][:] (one wave per channel, lanes over k: coalesced) ...
+    float *out = a.srows + (size_t)q * a.C * a.cp;
+    __shared__ unsigned char sIsDup[256];
+    sIsDup[c] = dup ? 1 : 0;
+    __syncthreads();
+    for (int cc = wv; cc < a.C; cc += 4) {                    // one wave per channel, lanes over k
+        const int rr = sArg[cc];
+        if (rr < 0) continue;
+        if (sIsDup[cc]) continue;
+        const float cf = sCoef[cc];
+        const int i = sIdx[cc];
+        for (int k = lane; k < a.cp; k += 64) out[(size_t)i * a.cp + k] = cf * a.W[(size_t)cc * a.cp + k];
     }
     __syncthreads();
-    const int nu = s_unique;
-    for (int e = tid; e < nu * a.cp; e += 256) sS[e] = 0.f;
-    __syncthreads();
+    // ... then the few merged channels are added in channel order (same thread per column: reproducible)
     if (tid < a.cp) {
         const int k = tid;
-#pragma unroll 4
-        for (int c = 0; c < a.C; ++c) {
-            const int i = sIdx[c];
-            const float w = a.W[(size_t)c * a.cp + k];
-            if (i >= 0) sS[i * a.cp + k] = fmaf(sCoef[c], w, sS[i * a.cp + k]);
+        for (int d = 0; d < s_ndup; ++d) {
+            const int cc = sDup[d];
+            out[(size_t)sIdx[cc] * a.cp + k] = fmaf(sCoef[cc], a.W[(size_t)cc * a.cp + k], out[(size_t)sIdx[cc] * a.cp + k]);
         }
     }
-    __syncthreads();
-    for (int e = tid; e < nu * a.cp; e += 256) a.srows[(size_t)q * a.C * a.cp + e] = sS[e];
-    for (int c = tid; c < a.C; c += 256)
-        if (sIdx[c] >= 0) a.srow_row[(size_t)q * a.C + sIdx[c]] = sArg[c];      // same value from every channel of a merged row
-    if (tid == 0) a.srow_cnt[q] = nu;
+}
+
+int sparse_rows(const SparseRows &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.srows && a.srow_row && a.srow_cnt, "sparse_rows: null pointer");
+    AMPNET_REQUIRE(a.cp <= 256 && a.C <= 256, "sparse_rows: C=%d cp=%d", a.C, a.cp);
+    hipLaunchKernelGGL(sparse_rows_kernel, dim3(a.Q), dim3(256), 0, st, a);
+    return check_launch("sparse_rows_kernel");
 }
 
 // one workgroup per window, thread = column; walks the window's merged rows in order (reproducible sums)
@@ -552,21 +580,6 @@ int sparse_fix(const SparseFix &a, hipStream_t st)
     AMPNET_REQUIRE(a.cp <= 128, "sparse_fix: cp=%d", a.cp);
     hipLaunchKernelGGL(sparse_fix_kernel, dim3(a.Q), dim3(128), 0, st, a);
     return check_launch("sparse_fix_kernel");
-}
-
-int sparse_rows(const SparseRows &a, hipStream_t st)
-{
-    AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.srows && a.srow_row && a.srow_cnt, "sparse_rows: null pointer");
-    AMPNET_REQUIRE(a.cp <= 256 && a.C <= 256, "sparse_rows: C=%d cp=%d", a.C, a.cp);
-    const size_t lds = (size_t)(a.C * a.cp + 3 * a.C) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sparse_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "sparse_rows: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sparse_rows_kernel, dim3(a.Q), dim3(256), lds, st, a);
-    return check_launch("sparse_rows_kernel");
 }
 
 // one thread per (j, k) of G (and row j == cp for c0), loop over the C contracted channels

@@ -175,6 +175,7 @@ struct EncRun {
         f.Q = fc ? s.n_slots : s.Q;
         f.chunks = fc ? s.fc_chunks : s.chunks;
         f.chunk_rows = fc ? s.fc_chunk_rows : s.chunk_rows;
+        f.uniform_rows = fc ? s.fc_rows : ((long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0);
         f.n_slots = s.n_slots; f.C = ws.bn[bn].C;
         f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
         f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;

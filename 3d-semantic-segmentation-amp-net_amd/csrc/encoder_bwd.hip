@@ -149,6 +149,7 @@ struct EncBwd {
             BnBwdFinalize fz;
             fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
             fz.Q = s.Q; fz.chunks = s.chunks; fz.n_slots = s.n_slots; fz.C = cp;
+            fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
             fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
             fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
             TRY(bn_bwd_finalize(fz, st));
@@ -211,6 +212,7 @@ struct EncBwd {
         BnBwdFinalize fz;
         fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
         fz.Q = s.Q; fz.chunks = s.chunks + 1; fz.n_slots = s.n_slots; fz.C = 128;
+        fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
         fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
         fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
         return bn_bwd_finalize(fz, st);

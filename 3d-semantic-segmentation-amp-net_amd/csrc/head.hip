@@ -142,6 +142,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         BnFinalize f;
         f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.chunk_rows = s.chunk_rows;
         f.win_off = win_off; f.Q = Q; f.chunks = s.chunks; f.n_slots = 1; f.C = b.C;
+        f.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
         f.gamma = P[wi]; f.beta = P[bi];
         f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
         return bn_finalize(f, st);

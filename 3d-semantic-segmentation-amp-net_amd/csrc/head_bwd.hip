@@ -315,6 +315,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
         TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, G[HP_CONV4_B], C, 0, st));
         BnBwdFinalize fz;
         fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = b.tot_off; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
+        fz.uniform_rows = R;
         fz.gamma = P[HP_BN3_W]; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
         fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
         TRY(bn_bwd_finalize(fz, st));
@@ -338,6 +339,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
         TRY(pw_dgrad(d, st));
         BnBwdFinalize fz;
         fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = s.chunks; fz.n_slots = 1; fz.C = 128;
+        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
         fz.gamma = P[HP_BN2_W]; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
         fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
         TRY(bn_bwd_finalize(fz, st));

@@ -68,6 +68,7 @@ int pw_input(const PwInput &a, hipStream_t st);
 struct BnFinalize {
     const float *part_sum = nullptr, *part_sq = nullptr;   // [Q * chunks, C] chunk mean, chunk M2
     int chunk_rows = 512;
+    int uniform_rows = 0;          // > 0: every window has this many rows (no win_off look-ups in the loops)
     const int *win_off = nullptr;
     int Q = 0, chunks = 1, n_slots = 1, C = 0;
     const float *gamma = nullptr, *beta = nullptr;
@@ -212,6 +213,7 @@ int reduce_windows(const float *part, int Q, long stride, int rows, int cols, in
 struct BnBwdFinalize {
     const float *part_a = nullptr, *part_b = nullptr;   // [Q * chunks, C]
     const int *win_off = nullptr;                       // rows per slot are counted from it
+    int uniform_rows = 0;                               // > 0: every window has this many rows
     int Q = 0, chunks = 1, n_slots = 1, C = 0;
     const float *gamma = nullptr, *mean = nullptr, *invstd = nullptr;   // gamma [C]; mean / invstd [n_slots, C]
     float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;  // [n_slots, C]

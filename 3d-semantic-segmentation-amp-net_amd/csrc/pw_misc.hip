@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
     double n = 0.0, sm = 0.0;
     for (int e = g; e < total; e += FIN_G) {
         const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
-        const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
+        const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
+        const int rows = min(wrows - ch * a.chunk_rows, a.chunk_rows);
         if (rows <= 0 || !ok) continue;
         n += (double)rows;
         sm += (double)rows * (double)a.part_sum[(size_t)(q * a.chunks + ch) * a.C + c];
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
     double m2 = 0.0;
     for (int e = g; e < total; e += FIN_G) {
         const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
-        const int rows = min(a.win_off[q + 1] - a.win_off[q] - ch * a.chunk_rows, a.chunk_rows);
+        const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
+        const int rows = min(wrows - ch * a.chunk_rows, a.chunk_rows);
         if (rows <= 0 || !ok) continue;
         const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
         const double d = (double)a.part_sum[o] - mean;
