@@ -70,6 +70,29 @@ def profile_read():
     return out
 
 
+def pmc_traffic_for(name):
+    """HBM bytes per launch (read + write) of the kernel bench.py calls `name`, from the rocprofv3 PMC passes summarised
+    in profiles/pmc_traffic.json (profiles/pmc_traffic.py; FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact).  None when the
+    file or an unambiguous match is missing."""
+    import re
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    m = re.match(r"pw_gemm<(\d+),(\d+)>(.*)", name)
+    if not (os.path.exists(path) and m):
+        return None
+    sym = f"ampnet::pw_gemm_kernel<{m.group(1)}, {int(m.group(2)) // 32}>|grid="
+    table = json.load(open(path))
+    cands = sorted(((int(k.split("=")[1]), v) for k, v in table.items() if k.startswith(sym)), key=lambda kv: -kv[0])
+    if not cands:
+        return None
+    if "+pool" in m.group(3):                       # the pooled 128 -> 256 launches: two column blocks = the largest grid
+        v = cands[0][1]
+    elif len(cands) == 1:
+        v = cands[0][1]
+    else:
+        return None
+    return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
+
+
 def roofline_from(rows):
     if not rows:
         return None
@@ -79,11 +102,12 @@ def roofline_from(rows):
     if intensity >= RIDGE:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4), traffic=None, launch_ms=round(per_ms, 4),
+                    frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4), traffic=pmc_traffic_for(top["name"]),
+                    algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
                     launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None, launch_ms=round(per_ms, 4), launches=int(top["calls"]),
+                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=pmc_traffic_for(top["name"]), launch_ms=round(per_ms, 4), launches=int(top["calls"]),
                 share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
 
 

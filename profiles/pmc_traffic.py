@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md
+prescribes) into HBM bytes per launch for the kernels bench.py names in its `roofline` object.
+
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/WRITE_SIZE -- python3 bench.py ...
+  python profiles/pmc_traffic.py gpurun_out/pmc profiles/pmc_traffic.json
+
+gfx950 corrections: FETCH_SIZE is in KiB and reports HALF of the bytes of wide coalesced reads (x 2); WRITE_SIZE in KiB
+reads exact.  A bench.py event name such as `pw_gemm<128,128>+pool` is a subset of the launches of one kernel symbol
+(`pw_gemm_kernel<128, 4>`); the subset is identified by its grid size (the pooled 128->256 launches have two column
+blocks, i.e. the largest grid of that symbol)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_dispatch(dirname, counter):
+    f = glob.glob(f"{dirname}/{counter}/*/*counter_collection.csv")
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == counter:
+            out[r["Kernel_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    return out
+
+
+def main(src, dst):
+    fe, wr = per_dispatch(src, "FETCH_SIZE"), per_dispatch(src, "WRITE_SIZE")
+    res = {}
+    for sym, rows in fe.items():
+        grids = sorted({g for g, _ in rows})
+        for g in grids:
+            rd = [v for gg, v in rows if gg == g]
+            ww = [v for gg, v in wr.get(sym, []) if gg == g]
+            key = f"{sym.split('(')[0].replace('void ', '')}|grid={g}"
+            res[key] = {"launches": len(rd), "read_bytes": sum(rd) / len(rd) * 1024 * 2,
+                        "write_bytes": (sum(ww) / len(ww) * 1024) if ww else None}
+    json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+    print(f"wrote {dst}: {len(res)} (kernel, grid) entries")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
