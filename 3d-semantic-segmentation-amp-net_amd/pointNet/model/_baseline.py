@@ -1,0 +1,117 @@
+"""Shared machinery of the two baseline PointNet drop-ins (pointnet.py, light_pointnet_256.py): parameter holders with
+the reference's state_dict keys and the eval forward through the C ABI (include/ampnet_hip.h:
+ampnet_pointnet_seg_fwd_f32, csrc/baseline.hip).  SURVEY row a12: BASELINE.json config 1 is the reference's CPU
+plumbing case; only the eval forward runs on the HIP path, training this model raises."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+from .pointnetAtt import _BN, _Conv, _Linear
+
+N_LAYERS = 21          # AMPNET_POINTNET_LAYERS
+
+
+class TnetHolder(nn.Module):
+    def __init__(self, input_dim, output_dim, G, F1, F2, bias, device):
+        super().__init__()
+        self.output_dim = output_dim
+        self.conv_1 = _Conv(input_dim, 64, bias, device)
+        self.conv_2 = _Conv(64, 128, bias, device)
+        self.conv_3 = _Conv(128, G, bias, device)
+        self.bn_1, self.bn_2, self.bn_3 = _BN(64, device), _BN(128, device), _BN(G, device)
+        self.bn_4, self.bn_5 = _BN(F1, device), _BN(F2, device)
+        self.fc_1 = _Linear(G, F1, bias, device)
+        self.fc_2 = _Linear(F1, F2, bias, device)
+        self.fc_3 = _Linear(F2, output_dim * output_dim, True, device)
+
+    def forward(self, x):
+        raise _lib.AmpnetError("TransformationNet runs inside SegmentationPointNet's HIP launch sequence")
+
+    def layers(self):
+        return [(self.conv_1, self.bn_1), (self.conv_2, self.bn_2), (self.conv_3, self.bn_3),
+                (self.fc_1, self.bn_4), (self.fc_2, self.bn_5), (self.fc_3, None)]
+
+
+class BaseHolder(nn.Module):
+    def __init__(self, point_dimension, return_local_features, G, F1, F2, bias, device):
+        super().__init__()
+        self.return_local_features = return_local_features
+        self.input_transform = TnetHolder(point_dimension, point_dimension, G, F1, F2, bias, device)
+        self.feature_transform = TnetHolder(64, 64, G, F1, F2, bias, device)
+        self.conv_1 = _Conv(9, 64, bias, device)
+        self.conv_2 = _Conv(64, 64, bias, device)
+        self.conv_3 = _Conv(64, 64, bias, device)
+        self.conv_4 = _Conv(64, 128, bias, device)
+        self.conv_5 = _Conv(128, G, bias, device)
+        self.bn_1, self.bn_2, self.bn_3 = _BN(64, device), _BN(64, device), _BN(64, device)
+        self.bn_4, self.bn_5 = _BN(128, device), _BN(G, device)
+
+    def forward(self, x):
+        raise _lib.AmpnetError("the baseline BasePointNet runs inside SegmentationPointNet's HIP launch sequence")
+
+    def layers(self):
+        return (self.input_transform.layers() + self.feature_transform.layers()
+                + [(self.conv_1, self.bn_1), (self.conv_2, self.bn_2), (self.conv_3, self.bn_3),
+                   (self.conv_4, self.bn_4), (self.conv_5, self.bn_5)])
+
+
+class SegHolder(nn.Module):
+    """Subclasses set VARIANT / T_DIM / widths and build self.base_pointnet + conv_1..4, bn_1..3."""
+    VARIANT = None
+    T_DIM = None
+
+    def _init_head(self, num_classes, G, H1, H2, H3, device):
+        self.num_classes = num_classes
+        self.conv_1 = _Conv(G + 64, H1, True, device)
+        self.conv_2 = _Conv(H1, H2, True, device)
+        self.conv_3 = _Conv(H2, H3, True, device)
+        self.conv_4 = _Conv(H3, num_classes, True, device)
+        self.bn_1, self.bn_2, self.bn_3 = _BN(H1, device), _BN(H2, device), _BN(H3, device)
+        self._ws = ops.Workspace()
+        self._key, self._arr, self._keep = None, None, None
+
+    def _layer_table(self):
+        layers = self.base_pointnet.layers() + [(self.conv_1, self.bn_1), (self.conv_2, self.bn_2),
+                                                (self.conv_3, self.bn_3), (self.conv_4, None)]
+        assert len(layers) == N_LAYERS
+        tensors = []
+        for lin, bn in layers:
+            tensors += [lin.weight, getattr(lin, "bias", None)]
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [None] * 4
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
+        if key != self._key:
+            arr = (ctypes.c_void_p * (6 * N_LAYERS))()
+            for i, t in enumerate(tensors):
+                if t is not None:
+                    _lib.require_gpu(t, "SegmentationPointNet parameter")
+                    if t.dtype != torch.float32 or not t.is_contiguous():
+                        raise _lib.AmpnetError("SegmentationPointNet parameters must be contiguous float32")
+                arr[i] = None if t is None else t.data_ptr()
+            self._key, self._arr, self._keep = key, arr, tensors
+        return self._arr
+
+    def forward(self, x):
+        """x [B, N, 9] -> (logits [B, num_classes, N], feature_transform [B, 64, 64])."""
+        if self.training:
+            raise _lib.AmpnetError("the baseline PointNet is eval-only on the HIP path (BASELINE.json config 1 is the "
+                                   "reference's CPU plumbing case); call .eval()")
+        _lib.require_gpu(x, "x")
+        if x.dim() != 3 or x.shape[2] != 9 or x.dtype != torch.float32:
+            raise _lib.AmpnetError(f"SegmentationPointNet: x must be [B, N, 9] float32, got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B, N, _ = x.shape
+        dev = x.device
+        L = _lib.lib()
+        L.ampnet_pointnet_seg_workspace_bytes.restype = ctypes.c_size_t
+        need = L.ampnet_pointnet_seg_workspace_bytes(self.VARIANT, B, N, self.num_classes)
+        buf = self._ws.get(need, dev)
+        logits = torch.empty((B, self.num_classes, N), dtype=torch.float32, device=dev)
+        feat_T = torch.empty((B, 64, 64), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.ampnet_pointnet_seg_fwd_f32(self._layer_table(), self.VARIANT, _lib.ptr(x), B, N, self.num_classes,
+                                               _lib.ptr(logits), _lib.ptr(feat_T), _lib.ptr(buf),
+                                               ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+        _lib.check(rc, "ampnet_pointnet_seg_fwd_f32")
+        return logits, feat_T

@@ -159,6 +159,24 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- a12: baseline single-window PointNet segmentation, eval forward -----------------------------------------
+ * replaces SegmentationPointNet.forward (module.eval()) of pointNet/model/pointnet.py:128-154 (variant 0: 1024-d,
+ * convolutions with bias, T-Net on x[:, :, :3], :71) and of pointNet/model/light_pointnet_256.py:128-153 (variant 1:
+ * 256-d, no conv / fc bias, T-Net on x[:, :, :2], :71).  BASELINE.json config 1 ([4, 512, 9]) is the reference's CPU
+ * plumbing case: this entry exists for parity and is not tuned.
+ *   layers_host  [AMPNET_POINTNET_LAYERS * 6] device pointers, per layer {weight, bias, bn.weight, bn.bias,
+ *                bn.running_mean, bn.running_var}; bias and the four BatchNorm pointers may be NULL.  Layer order:
+ *                0-5   base_pointnet.input_transform   conv_1 conv_2 conv_3 fc_1 fc_2 fc_3   (bn_1 .. bn_5, none)
+ *                6-11  base_pointnet.feature_transform  (same)
+ *                12-16 base_pointnet.conv_1 .. conv_5   (bn_1 .. bn_5)
+ *                17-20 conv_1 .. conv_4                 (bn_1 .. bn_3, none)
+ *   x [B, N, 9] -> logits [B, n_classes, N]; feat_T [B, 64, 64] (optional) = feature_transform            */
+#define AMPNET_POINTNET_LAYERS 21
+size_t ampnet_pointnet_seg_workspace_bytes(int variant, int B, int N, int n_classes);
+int ampnet_pointnet_seg_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N,
+                                int n_classes, float *logits, float *feat_T, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
 /* ---- a7: optimiser -----------------------------------------------------------------------------------------
  * replaces torch.optim.Adam.step as the reference configures it (train_pointnet-attention.py:140-141,469-470):
  * betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad; `step` counts from 1.  One launch updates a list of

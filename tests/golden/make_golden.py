@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import baseline_state                      # noqa: E402
 
 pkg = importlib.import_module("3d-semantic-segmentation-amp-net_amd")
 synth = importlib.import_module("3d-semantic-segmentation-amp-net_amd.synthetic")
@@ -264,32 +266,22 @@ def sec_dataset():
 
 
 def sec_baseline():
-    """a12 / config 1: pointNet/model/pointnet.py:128-154 SegmentationPointNet(5, point_dimension=3), eval, [4,512,9]."""
+    """a12 / config 1: pointNet/model/pointnet.py:128-154 SegmentationPointNet(5, point_dimension=3) and
+    pointNet/model/light_pointnet_256.py:128-153 SegmentationPointNet(5, point_dimension=2, device='cpu'), eval, [4,512,9]."""
     from pointNet.model.pointnet import SegmentationPointNet
-    torch.manual_seed(0)
-    net = SegmentationPointNet(num_classes=5, point_dimension=3)
-    table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
-    sd = {}
-    for i, (k, shp) in enumerate(table.items()):
-        if k.endswith("running_mean"):
-            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, -0.3, 0.3))
-        elif k.endswith("running_var"):
-            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, 0.5, 1.5))
-        elif ".bn" in k or k.startswith("bn"):
-            lo, hi = (0.5, 1.5) if k.endswith("weight") else (-0.2, 0.2)
-            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, lo, hi))
-        else:
-            fan = int(np.prod(shp[1:])) if len(shp) > 1 else int(shp[0])
-            b = 1.0 / np.sqrt(fan)
-            sd[k] = torch.from_numpy(synth.uniform(9000 + i, shp, -b, b))
-    net.load_state_dict(sd, strict=False)
-    net.eval()
-    x = torch.from_numpy(synth.windows(81, 4, 512))
-    with torch.no_grad():
-        logits, ft = net(x)
-    names = np.array(list(table.keys()))
-    shapes = np.array([";".join(map(str, s)) for s in table.values()])
-    save("baseline", logits=logits.numpy(), feat_T=ft.numpy(), names=names, shapes=shapes)
+    from pointNet.model.light_pointnet_256 import SegmentationPointNet as LightSeg
+    for tag, net, base in (("baseline", SegmentationPointNet(num_classes=5, point_dimension=3), 9000),
+                           ("baseline_light", LightSeg(num_classes=5, point_dimension=2, device="cpu"), 9500)):
+        table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+        sd = {k: torch.from_numpy(v) for k, v in baseline_state(synth, table, base).items()}
+        net.load_state_dict(sd, strict=False)
+        net.eval()
+        x = torch.from_numpy(synth.windows(81, 4, 512))
+        with torch.no_grad():
+            logits, ft = net(x)
+        names = np.array(list(table.keys()))
+        shapes = np.array([";".join(map(str, s)) for s in table.values()])
+        save(tag, logits=logits.numpy(), feat_T=ft.numpy(), names=names, shapes=shapes, seed_base=np.array([base]))
 
 
 SECTIONS = dict(fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,

@@ -30,3 +30,22 @@ def replay_augment(seed, pc, tg, train):
             pc[:, :, :, w] = pc[:, :, :, w][:, pidx, :]
             tg[:, :, w] = tg[:, :, w][:, pidx]
     return pc, tg
+
+
+def baseline_state(synth, table, base):
+    """Seeded state_dict {key: ndarray} for a baseline PointNet from {key: shape} (make_golden.py:sec_baseline uses the
+    same function, so the fixture's outputs belong to exactly these weights)."""
+    sd = {}
+    for i, (k, shp) in enumerate(table.items()):
+        if k.endswith("running_mean"):
+            sd[k] = synth.uniform(base + i, shp, -0.3, 0.3)
+        elif k.endswith("running_var"):
+            sd[k] = synth.uniform(base + i, shp, 0.5, 1.5)
+        elif ".bn" in k or k.startswith("bn"):
+            lo, hi = (0.5, 1.5) if k.endswith("weight") else (-0.2, 0.2)
+            sd[k] = synth.uniform(base + i, shp, lo, hi)
+        else:
+            fan = int(np.prod(shp[1:])) if len(shp) > 1 else int(shp[0])
+            b = 1.0 / np.sqrt(fan)
+            sd[k] = synth.uniform(base + i, shp, -b, b)
+    return sd
