@@ -16,9 +16,10 @@ __global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinal
     const int slot = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    const int part_per_slot = a.part_Q > 0 ? (a.part_Q - slot + a.n_slots - 1) / a.n_slots : per_slot;
     double sa = 0.0, sb = 0.0;
     if (c < a.C) {
-        const int total = per_slot * a.chunks;
+        const int total = part_per_slot * a.chunks;
         for (int e = g; e < total; e += BFIN_G) {
             const int q = slot + (e / a.chunks) * a.n_slots;
             const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;

@@ -90,8 +90,10 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.zext_c = c.take<float>(Q * 256);
     ws.fc_off = c.take<int>((size_t)s.n_slots + 1);
     const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
-    ws.part_sum = c.take<float>(np);
-    ws.part_sq = c.take<float>(np);
+    // the fused backward indexes its BatchNorm sums by workgroup (<= 256 + n_slots of them) + one row per window
+    const size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256;
+    ws.part_sum = c.take<float>(np_bwd);
+    ws.part_sq = c.take<float>(np_bwd);
     ws.part_max = c.take<float>(np);
     ws.part_min = c.take<float>(np);
     ws.part_amax = c.take<int>(np);

@@ -5,6 +5,7 @@
 //     [pool_bwd | bn_bwd_finalize]  ->  pw_wgrad(l) + reduce_windows  ->  pw_dgrad(l)  -> next layer's finalize
 // using only what the train-mode forward left in its workspace (pre-BatchNorm z, batch mean / invstd / affine,
 // argmax rows) plus two ping-pong dy buffers.  Train mode only (batch statistics).
+#include <cstdlib>
 #include "bwd_misc.h"
 #include "encoder.h"
 
@@ -101,6 +102,7 @@ struct EncBwd {
     float *const *G;
     const int *win_off;
     const float *gamma[BN_ENC_COUNT];
+    bool fused = true;         // AMPNET_FUSED_BWD=0 falls back to the separate pw_wgrad / pw_dgrad launches
 
     GradSrc dense(const float *dy, const float *z, int bn, int C) const
     {
@@ -156,6 +158,45 @@ struct EncBwd {
         }
         return AMPNET_OK;
     }
+    // weight gradient + data gradient of one shared layer in one pass over (dy, z, z_prev) (pw_bwd_fused.hip); prev_bn < 0:
+    // the layer's input is prev_z itself (no activation, no mask, no sums)
+    int layer_bwd(const GradSrc &g, const float *W, float *dW, const float *prev_z, int prev_bn, int cy, const float *add, float *out) const
+    {
+        if (!fused || !pw_bwd_supported(g.C, cy)) {
+            ActSrc y;
+            if (prev_bn >= 0) y = act(prev_z, prev_bn, cy);
+            else { y.z = prev_z; y.C = cy; }
+            TRY(wgrad(g, y, dW));
+            return dgrad(g, W, cy, prev_bn >= 0 ? prev_z : nullptr, prev_bn, cy, add, out);
+        }
+        PwBwd p;
+        p.g = g;
+        if (prev_bn >= 0) {
+            p.prev = act(prev_z, prev_bn, cy);
+            p.prev_mean = f.bn[prev_bn].mean; p.prev_invstd = f.bn[prev_bn].invstd;
+            p.part_a = f.part_sum; p.part_b = f.part_sq;
+        } else {
+            p.prev.z = prev_z; p.prev.C = cy;
+        }
+        p.W = W; p.ldw = cy; p.add = add; p.out = out; p.dWpart = b.wpart;
+        p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
+        p.blocks_per_slot = pw_bwd_blocks(s.Q, s.n_slots, s.max_rows);
+        const int nblk = p.blocks_per_slot * s.n_slots;
+        TRY(pw_bwd_fused(p, st));
+        TRY(reduce_windows(b.wpart, nblk, (long)g.C * cy, g.C, cy, cy, dW, cy, 0, st));
+        if (prev_bn >= 0) TRY(finalize_prev(prev_bn, cy, nblk, 1));
+        return AMPNET_OK;
+    }
+    int finalize_prev(int prev_bn, int cp, int part_Q, int chunks) const
+    {
+        BnBwdFinalize fz;
+        fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
+        fz.Q = s.Q; fz.chunks = chunks; fz.part_Q = part_Q; fz.n_slots = s.n_slots; fz.C = cp;
+        fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
+        fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
+        fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
+        return bn_bwd_finalize(fz, st);
+    }
     // Backward of a 128 -> 256 layer followed by BatchNorm + ReLU + MaxPool, WITHOUT its [rows, 256] output.
     // With z = W a, dz = P1 dy + P2 z + P3 and dy non-zero only on the argmax rows (kernels.h, "backward of a max-pooled
     // layer"): the data gradient is a 128 -> 128 GEMM with per-slot weights G = W^T diag(P2) W plus c0 = P3 W plus a few
@@ -174,6 +215,37 @@ struct EncBwd {
         sr.Q = s.Q; sr.n_slots = s.n_slots; sr.srows = b.srows; sr.srow_row = b.srow_row; sr.srow_cnt = b.srow_cnt;
         TRY(sparse_rows(sr, st));
         TRY(slot_mats(W, b.bn[bn].P2, b.bn[bn].P3, s.n_slots, 256, 128, b.Gm, b.c0, st));
+        PooledWgrad pw;
+        pw.W = W; pw.P1 = b.bn[bn].P1; pw.P2 = b.bn[bn].P2; pw.P3 = b.bn[bn].P3; pw.gram = b.gram; pw.asum = b.asum;
+        pw.arg = arg; pw.dpm = b.dpm; pw.slot_major = slot_major;
+        pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift;
+        pw.Q = s.Q; pw.n_slots = s.n_slots; pw.dW = dW;
+        SparseFix sf;
+        sf.srows = b.srows; sf.srow_row = b.srow_row; sf.srow_cnt = b.srow_cnt; sf.z_prev = z_prev;
+        sf.s_prev = f.bn[prev_bn].scale; sf.t_prev = f.bn[prev_bn].shift; sf.mean_prev = f.bn[prev_bn].mean; sf.invstd_prev = f.bn[prev_bn].invstd;
+        sf.Q = s.Q; sf.n_slots = s.n_slots; sf.out = dy_out;
+        if (fused) {
+            // one pass over z_prev: per-slot Gram matrix + column sums of a = relu(bn_prev(z_prev)) AND
+            // dy_prev = (a G[slot] + c0[slot]) masked by the previous layer's ReLU, with its BatchNorm-backward sums
+            PwBwd p;
+            p.g.z = z_prev; p.g.C = 128; p.g.act = 1; p.g.P2 = f.bn[prev_bn].scale; p.g.P3 = f.bn[prev_bn].shift;
+            p.prev = act(z_prev, prev_bn, 128);
+            p.prev_mean = f.bn[prev_bn].mean; p.prev_invstd = f.bn[prev_bn].invstd;
+            p.W = b.Gm; p.ldw = 128; p.w_slot_stride = 128 * 128; p.bias_slot = b.c0;
+            p.out = dy_out; p.dWpart = b.wpart; p.dbpart = b.dbpart; p.part_a = f.part_sum; p.part_b = f.part_sq;
+            p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
+            p.blocks_per_slot = pw_bwd_blocks(s.Q, s.n_slots, s.max_rows);
+            const int nblk = p.blocks_per_slot * s.n_slots;
+            TRY(pw_bwd_fused(p, st));
+            TRY(reduce_slots(b.wpart, nblk, 1, s.n_slots, 128 * 128, b.gram, st));
+            TRY(reduce_slots(b.dbpart, nblk, 1, s.n_slots, 128, b.asum, st));
+            TRY(pooled_wgrad(pw, st));
+            // the scattered rows: added after the dense part, their share of the sums goes behind the workgroup partials
+            sf.part_a = f.part_sum + (size_t)nblk * 128; sf.part_b = f.part_sq + (size_t)nblk * 128;
+            sf.part_chunks = 1; sf.slot_idx = 0;
+            TRY(sparse_fix(sf, st));
+            return finalize_prev(prev_bn, 128, nblk + s.Q, 1);
+        }
         // Gram and column sums of a = relu(bn_prev(z_prev)) per slot, then dW
         {
             PwWgrad w;
@@ -185,11 +257,6 @@ struct EncBwd {
             TRY(pw_wgrad(w, st));
             TRY(reduce_slots(b.wpart, s.Q, w.chunks, s.n_slots, 128 * 128, b.gram, st));
             TRY(reduce_slots(b.dbpart, s.Q, w.chunks, s.n_slots, 128, b.asum, st));
-            PooledWgrad pw;
-            pw.W = W; pw.P1 = b.bn[bn].P1; pw.P2 = b.bn[bn].P2; pw.P3 = b.bn[bn].P3; pw.gram = b.gram; pw.asum = b.asum;
-            pw.arg = arg; pw.dpm = b.dpm; pw.slot_major = slot_major;
-            pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift;
-            pw.Q = s.Q; pw.n_slots = s.n_slots; pw.dW = dW;
             TRY(pooled_wgrad(pw, st));
         }
         // data gradient: dy_prev = (a G[slot] + c0[slot] + scattered rows) masked by the previous layer's ReLU
@@ -203,19 +270,10 @@ struct EncBwd {
         d.win_off = win_off; d.Q = s.Q; d.n_slots = s.n_slots; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = s.R;
         TRY(pw_dgrad(d, st));
         // the scattered rows: added after the dense part, with their share of the BatchNorm-backward sums in an extra slot
-        SparseFix sf;
-        sf.srows = b.srows; sf.srow_row = b.srow_row; sf.srow_cnt = b.srow_cnt; sf.z_prev = z_prev;
-        sf.s_prev = f.bn[prev_bn].scale; sf.t_prev = f.bn[prev_bn].shift; sf.mean_prev = f.bn[prev_bn].mean; sf.invstd_prev = f.bn[prev_bn].invstd;
-        sf.Q = s.Q; sf.n_slots = s.n_slots; sf.out = dy_out; sf.part_a = f.part_sum; sf.part_b = f.part_sq;
+        sf.part_a = f.part_sum; sf.part_b = f.part_sq;
         sf.part_chunks = s.chunks + 1; sf.slot_idx = s.chunks;
         TRY(sparse_fix(sf, st));
-        BnBwdFinalize fz;
-        fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
-        fz.Q = s.Q; fz.chunks = s.chunks + 1; fz.n_slots = s.n_slots; fz.C = 128;
-        fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
-        fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
-        fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
-        return bn_bwd_finalize(fz, st);
+        return finalize_prev(prev_bn, 128, 0, s.chunks + 1);
     }
 
     // T-Net FC head backward: g3 [Q, kk] (slot-major rows) -> parameter grads, d_pool [Q, 256]
@@ -273,6 +331,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     e.P = params_host;
     e.G = grads_host;
     e.win_off = win_off;
+    {
+        const char *env = getenv("AMPNET_FUSED_BWD");
+        e.fused = !(env && env[0] == '0');
+    }
     const float *const *P = params_host;
     float *const *G = grads_host;
     for (int i = 0; i < 5; ++i) {
@@ -291,21 +353,16 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     TRY(e.pooled_layer(d_global, 0, f.arg_c, f.zext_c, BN_C6, P[EP_CONV6], G[EP_CONV6], f.z_c5, BN_C5, b.dyA));
     {
         const GradSrc g5 = e.dense(b.dyA, f.z_c5, BN_C5, 128);
-        TRY(e.wgrad(g5, e.act(f.z_c4, BN_C4, 128), G[EP_CONV5]));
-        TRY(e.dgrad(g5, P[EP_CONV5], 128, f.z_c4, BN_C4, 128, nullptr, b.dyB));
+        TRY(e.layer_bwd(g5, P[EP_CONV5], G[EP_CONV5], f.z_c4, BN_C4, 128, nullptr, b.dyB));
     }
     {
         const GradSrc g4 = e.dense(b.dyB, f.z_c4, BN_C4, 128);
-        TRY(e.wgrad(g4, e.act(f.z_c3, BN_C3, 64), G[EP_CONV4]));
-        TRY(e.dgrad(g4, P[EP_CONV4], 64, f.z_c3, BN_C3, 64, nullptr, b.dyA));
+        TRY(e.layer_bwd(g4, P[EP_CONV4], G[EP_CONV4], f.z_c3, BN_C3, 64, nullptr, b.dyA));
     }
     {
         // conv_3 reads `local` (the torch.bmm output, not activated); the head's gradient d_local joins here
         const GradSrc g3 = e.dense(b.dyA, f.z_c3, BN_C3, 64);
-        ActSrc yl;
-        yl.z = local; yl.C = 64;
-        TRY(e.wgrad(g3, yl, G[EP_CONV3]));
-        TRY(e.dgrad(g3, P[EP_CONV3], 64, nullptr, -1, 64, d_local, b.d_local));
+        TRY(e.layer_bwd(g3, P[EP_CONV3], G[EP_CONV3], local, -1, 64, d_local, b.d_local));
     }
     // ---- local = h x T64[window]: dT64 (per window, no reduction) and d_h ---------------------------------
     {
@@ -330,19 +387,16 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     TRY(e.pooled_layer(b.d_pool, 1, f.arg_f, f.zext_f, BN_F3, P[EP_FT + TP_CONV3], G[EP_FT + TP_CONV3], f.z_f2, BN_F2, b.dyA));
     {
         const GradSrc g = e.dense(b.dyA, f.z_f2, BN_F2, 128);
-        TRY(e.wgrad(g, e.act(f.z_f1, BN_F1, 64), G[EP_FT + TP_CONV2]));
-        TRY(e.dgrad(g, P[EP_FT + TP_CONV2], 64, f.z_f1, BN_F1, 64, nullptr, b.dyB));
+        TRY(e.layer_bwd(g, P[EP_FT + TP_CONV2], G[EP_FT + TP_CONV2], f.z_f1, BN_F1, 64, nullptr, b.dyB));
     }
     {
         const GradSrc g = e.dense(b.dyB, f.z_f1, BN_F1, 64);
-        TRY(e.wgrad(g, e.act(f.z_c2, BN_C2, 64), G[EP_FT + TP_CONV1]));
-        TRY(e.dgrad(g, P[EP_FT + TP_CONV1], 64, f.z_c2, BN_C2, 64, b.d_h, b.dyA));      // + the bmm path into h
+        TRY(e.layer_bwd(g, P[EP_FT + TP_CONV1], G[EP_FT + TP_CONV1], f.z_c2, BN_C2, 64, b.d_h, b.dyA));      // + the bmm path into h
     }
     // ---- conv_2, conv_1 -----------------------------------------------------------------------------------------
     {
         const GradSrc g = e.dense(b.dyA, f.z_c2, BN_C2, 64);
-        TRY(e.wgrad(g, e.act(f.z_c1, BN_C1, 64), G[EP_CONV2]));
-        TRY(e.dgrad(g, P[EP_CONV2], 64, f.z_c1, BN_C1, 64, nullptr, b.dyB));
+        TRY(e.layer_bwd(g, P[EP_CONV2], G[EP_CONV2], f.z_c1, BN_C1, 64, nullptr, b.dyB));
     }
     {
         PwInputWgrad w;
@@ -357,8 +411,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     TRY(e.pooled_layer(b.d_pool, 1, f.arg_t, f.zext_t, BN_T3, P[EP_IT + TP_CONV3], G[EP_IT + TP_CONV3], f.z_t2, BN_T2, b.dyA));
     {
         const GradSrc g = e.dense(b.dyA, f.z_t2, BN_T2, 128);
-        TRY(e.wgrad(g, e.act(f.z_t1, BN_T1, 64), G[EP_IT + TP_CONV2]));
-        TRY(e.dgrad(g, P[EP_IT + TP_CONV2], 64, f.z_t1, BN_T1, 64, nullptr, b.dyB));
+        TRY(e.layer_bwd(g, P[EP_IT + TP_CONV2], G[EP_IT + TP_CONV2], f.z_t1, BN_T1, 64, nullptr, b.dyB));
     }
     {
         PwInputWgrad w;

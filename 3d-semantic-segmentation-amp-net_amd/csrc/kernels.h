@@ -202,6 +202,33 @@ struct PwWgrad {
 };
 int pw_wgrad(const PwWgrad &a, hipStream_t st);
 
+// Fused backward of one shared-weight layer z_l = a_{l-1} W^T with a_{l-1} = relu(bn(z_{l-1})) (or z_{l-1} itself):
+// ONE pass over (dy_l, z_l, z_{l-1}) produces both the weight-gradient partials and dy_{l-1} with the BatchNorm-backward
+// sums of layer l-1 (pw_bwd_fused.hip).  Persistent workgroups: grid = blocks_per_slot * n_slots, workgroup
+// (slot, j) = blockIdx.x % n_slots, / n_slots walks a contiguous share of the slot's windows, so every partial
+// (dWpart, dbpart, part_a / part_b) is indexed by blockIdx.x and belongs to exactly one slot (index % n_slots).
+struct PwBwd {
+    GradSrc g;                     // dense (dy, z, P1..P3 | P1 == nullptr: g = dy) or act (z, P2 = scale, P3 = shift); CX = g.C
+    ActSrc prev;                   // z_{l-1} [rows, CY]; s == nullptr: identity (no mask, no sums); no dropout here
+    const float *prev_mean = nullptr, *prev_invstd = nullptr;   // [n_slots, CY]
+    const float *W = nullptr;      // [CX][ldw] torch layout (row = output channel of layer l, column = input channel)
+    int ldw = 0;
+    long w_slot_stride = 0;        // != 0: per-slot weights at W + slot * w_slot_stride
+    const float *bias_slot = nullptr;   // [n_slots, CY] added to every dgrad row of the slot
+    const float *add = nullptr;    // [rows, CY] added to the dgrad output
+    float *out = nullptr;          // [rows, CY] dy_{l-1} (masked)
+    float *dWpart = nullptr;       // [grid][CX][CY]
+    float *dbpart = nullptr;       // [grid][CX] or nullptr: sum of g
+    float *part_a = nullptr, *part_b = nullptr;   // [grid][CY] or nullptr
+    const int *win_off = nullptr;
+    int Q = 0, n_slots = 1, max_rows = 0;
+    int blocks_per_slot = 0;       // filled by pw_bwd_blocks()
+    long rows_hint = 0;
+};
+int pw_bwd_blocks(int Q, int n_slots, int max_rows);     // blocks_per_slot for this shape (grid = that * n_slots)
+bool pw_bwd_supported(int cx, int cy);
+int pw_bwd_fused(const PwBwd &a, hipStream_t st);
+
 // dst[i] (= or +=) sum_q part[q * stride + i], i < n, fixed order; dst row-remap for strided destinations:
 // element i = (r, c) with c < cols -> dst[r * ld_dst + c]
 int reduce_windows(const float *part, int Q, long stride, int rows, int cols, int ld_part, float *dst, int ld_dst, int accumulate,
@@ -215,6 +242,7 @@ struct BnBwdFinalize {
     const int *win_off = nullptr;                       // rows per slot are counted from it
     int uniform_rows = 0;                               // > 0: every window has this many rows
     int Q = 0, chunks = 1, n_slots = 1, C = 0;
+    int part_Q = 0;                                     // > 0: the partial arrays hold part_Q * chunks rows (index % n_slots = slot)
     const float *gamma = nullptr, *mean = nullptr, *invstd = nullptr;   // gamma [C]; mean / invstd [n_slots, C]
     float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;  // [n_slots, C]
     float *slot_ab = nullptr;                           // [n_slots, C, 2]

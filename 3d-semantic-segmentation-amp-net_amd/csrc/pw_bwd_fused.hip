@@ -1,0 +1,353 @@
+// pw_bwd_fused.hip -- weight gradient AND data gradient of a shared-weight per-point layer in one pass.
+//
+// pw_wgrad and pw_dgrad (pw_bwd.hip) each stream (dy_l, z_l, z_{l-1}) from HBM; at 64..128 channels both sit on the
+// memory system, not on the matrix cores.  Here a workgroup stages one block of rows ONCE:
+//     sG[row][cx] = g = dy * P1 + z * P2 + P3   (or relu(z * P2 + P3) for the Gram form of the pooled layers)
+//     sZ[row][cy] = z_{l-1} (raw: the activation is applied when read, the ReLU mask / zhat come from the same tile)
+// and its 8 waves split by ROLE, one wave of each role per SIMD:
+//     waves 0-3 (W): dW[cx][cy] += sum_rows sG[row][cx] * act(sZ[row][cy])       accumulators live across the whole grid-stride
+//     waves 4-7 (D): out[row][cy] = mask * (sum_cx sG[row][cx] * W[cx][cy] + ...)  one 32 x 32 tile per wave, + the sums
+//                    sum dy_{l-1}, sum dy_{l-1} * zhat_{l-1} of the next BatchNorm backward
+// Both roles issue the same number of MFMAs per block of rows (it is the same rows x CX x CY product).
+// Workgroups are persistent: (slot, j) walks a contiguous share of the (window, chunk) items of its slot, so the
+// per-workgroup partials are few (grid of them, not windows x chunks), every one belongs to one BatchNorm slot, and
+// weights / constants are staged once.  Fixed assignment, no atomics: bitwise reproducible.
+#include "kernels.h"
+
+namespace ampnet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FB_THREADS = 512;
+constexpr int FB_ITEM_ROWS = 256;      // granularity of the work split inside a slot
+
+template <int CX, int CY, int ROWS>
+__global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
+{
+    constexpr int LDG = CX + 4, LDZ = CY + 4;
+    constexpr int TXN = CX / 32, TYN = CY / 32;
+    constexpr int WXN = (TXN == 4 && TYN == 2) ? 4 : 2, WYN = 4 / WXN;
+    constexpr int TXW = TXN / WXN, TYW = TYN / WYN;
+    constexpr int QX = CX / 4, QY = CY / 4, SX = FB_THREADS / QX, SY = FB_THREADS / QY;
+    constexpr int NIX = ROWS / SX, NIY = ROWS / SY;
+    static_assert((ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
+    static_assert(NIX >= 1 && NIY >= 1, "staging shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sG = smem;                               // [2][ROWS][LDG]
+    float *sZ = sG + 2 * ROWS * LDG;                // [2][ROWS][LDZ]
+    float *sWt = sZ + 2 * ROWS * LDZ;               // [CY][LDG]: sWt[j][k] = W[k][j]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
+    const bool x_act = a.g.act != 0;
+    const bool has_bn = a.g.P1 != nullptr && !x_act;
+    const bool same = x_act && a.g.z == a.prev.z;           // Gram form: one tensor feeds both tiles
+    const bool y_act = a.prev.s != nullptr;
+
+    // ---- work split: items = (window of this slot, chunk of FB_ITEM_ROWS rows), contiguous share per workgroup ----
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    const int cpw = (a.max_rows + FB_ITEM_ROWS - 1) / FB_ITEM_ROWS;
+    const int n_items = per_slot * cpw;
+    const int ipb = (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
+    const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
+
+    // ---- stage the transposed weight and load the per-thread constants ----
+    {
+        const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+        for (int e = tid; e < CX * (CY / 4); e += FB_THREADS) {
+            const int k = e % CX, j4 = e / CX;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Wsh + (size_t)k * a.ldw + 4 * j4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sWt[(4 * j4 + i) * LDG + k] = v[i];
+        }
+    }
+    const int cqx = tid % QX, rsx = tid / QX, cqy = tid % QY, rsy = tid / QY;
+    f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
+    if (has_bn) p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
+    if (has_bn || x_act) {
+        p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
+        p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
+    }
+
+    // ---- the walk over blocks of ROWS rows (crosses item boundaries so that the prefetch never drains) ----
+    struct Pos {
+        int item, row0, row_end;        // current block = rows [row0, min(row0 + ROWS, row_end))
+    };
+    auto open_item = [&](int item, Pos &p) -> bool {       // first block of the next non-empty item at or after `item`
+        for (; item < item_end; ++item) {
+            const int q = (item / cpw) * a.n_slots + slot, ch = item % cpw;
+            const int rb = a.win_off[q] + ch * FB_ITEM_ROWS;
+            const int re = min(a.win_off[q + 1], rb + FB_ITEM_ROWS);
+            if (rb < re) {
+                p.item = item;
+                p.row0 = rb;
+                p.row_end = re;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto advance = [&](Pos &p) -> bool {
+        if (p.row0 + ROWS < p.row_end) {
+            p.row0 += ROWS;
+            return true;
+        }
+        return open_item(p.item + 1, p);
+    };
+
+    f32x4 rx_dy[NIX], rx_z[NIX], ry_z[NIY];
+    auto load_regs = [&](const Pos &p) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int row = p.row0 + rsx + SX * i;
+            const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
+            if (has_bn || x_act) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+        }
+        if (!same) {
+#pragma unroll
+            for (int i = 0; i < NIY; ++i) {
+                const int row = p.row0 + rsy + SY * i;
+                const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+                ry_z[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
+            }
+        }
+    };
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    auto write_lds = [&](int buf, const Pos &p) {
+        float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int row = p.row0 + rsx + SX * i;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (row < p.row_end) {
+                if (x_act) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaxf(fmaf(rx_z[i][c], p2[c], p3[c]), 0.f);
+                } else if (has_bn) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaf(rx_dy[i][c], p1[c], fmaf(rx_z[i][c], p2[c], p3[c]));
+                } else {
+                    xv = rx_dy[i];
+                }
+                dbacc += xv;
+            }
+            *reinterpret_cast<f32x4 *>(g + (rsx + SX * i) * LDG + 4 * cqx) = xv;
+            if (same) *reinterpret_cast<f32x4 *>(z + (rsx + SX * i) * LDZ + 4 * cqx) = rx_z[i];   // CX == CY here
+        }
+        if (!same) {
+#pragma unroll
+            for (int i = 0; i < NIY; ++i) *reinterpret_cast<f32x4 *>(z + (rsy + SY * i) * LDZ + 4 * cqy) = ry_z[i];
+        }
+    };
+
+    // ---- role state ----
+    const bool w_role = wave < 4;
+    const int ww = wave & 3;
+    // W role: tiles (tx0 .. tx0 + TXW) x (ty0 .. ty0 + TYW)
+    const int tx0 = (ww / WYN) * TXW, ty0 = (ww % WYN) * TYW;
+    f32x16 acc_w[TXW][TYW];
+#pragma unroll
+    for (int i = 0; i < TXW; ++i)
+#pragma unroll
+        for (int j = 0; j < TYW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_w[i][j][e] = 0.f;
+    float wys[TYW], wyt[TYW];
+#pragma unroll
+    for (int j = 0; j < TYW; ++j) {
+        const int col = 32 * (ty0 + j) + r;
+        wys[j] = y_act ? a.prev.s[(size_t)slot * CY + col] : 1.0f;
+        wyt[j] = y_act ? a.prev.t[(size_t)slot * CY + col] : 0.0f;
+    }
+    // D role: tile (rt, ty), lane = output column
+    const int rt = ww / TYN, dty = ww % TYN, dcol = 32 * dty + r;
+    const float c_b = a.bias_slot ? a.bias_slot[(size_t)slot * CY + dcol] : 0.f;
+    const float c_s = y_act ? a.prev.s[(size_t)slot * CY + dcol] : 1.0f;
+    const float c_t = y_act ? a.prev.t[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_m = (y_act && a.prev_mean) ? a.prev_mean[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_i = (y_act && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
+    const bool do_part = a.part_a != nullptr;
+    float s_a = 0.f, s_b = 0.f;
+
+    Pos cur, nxt;
+    bool live = open_item(item_begin, cur);
+    if (live) load_regs(cur);
+    __syncthreads();                     // sWt staged
+    if (live) write_lds(0, cur);
+    __syncthreads();
+    int buf = 0;
+    while (live) {
+        nxt = cur;
+        const bool more = advance(nxt);
+        if (more) load_regs(nxt);
+        const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
+        if (w_role) {
+#pragma unroll 4
+            for (int s2 = 0; s2 < ROWS / 2; ++s2) {
+                const int kr = 2 * s2 + h;
+                float xa[TXW], yb[TYW];
+#pragma unroll
+                for (int i = 0; i < TXW; ++i) xa[i] = g[kr * LDG + 32 * (tx0 + i) + r];
+#pragma unroll
+                for (int j = 0; j < TYW; ++j) {
+                    const float zv = z[kr * LDZ + 32 * (ty0 + j) + r];
+                    yb[j] = y_act ? fmaxf(fmaf(zv, wys[j], wyt[j]), 0.f) : zv;
+                }
+#pragma unroll
+                for (int i = 0; i < TXW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TYW; ++j) acc_w[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc_w[i][j], 0, 0, 0);
+            }
+        } else {
+            // the optional addend: all sixteen loads in flight before the MFMAs
+            const int valid = min(ROWS, cur.row_end - cur.row0) - 32 * rt;       // rows of this tile that exist (may be <= 0)
+            const int trow0 = cur.row0 + 32 * rt;
+            float addv[16];
+            if (a.add) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    addv[e] = rr < valid ? a.add[(size_t)(trow0 + rr) * CY + dcol] : 0.f;
+                }
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc0[e] = 0.f;
+                acc1[e] = 0.f;
+            }
+            const float *ga = g + (32 * rt + r) * LDG + 4 * h;
+            const float *wb = sWt + dcol * LDG + 4 * h;
+#pragma unroll 4
+            for (int j = 0; j < CX / 8; j += 2) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(ga + 8 * j), w0 = *reinterpret_cast<const f32x4 *>(wb + 8 * j);
+                const f32x4 g1 = *reinterpret_cast<const f32x4 *>(ga + 8 * j + 8), w1 = *reinterpret_cast<const f32x4 *>(wb + 8 * j + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[i], w0[i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], w1[i], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (rr >= valid) continue;
+                float v = acc0[e] + acc1[e] + c_b;
+                if (a.add) v += addv[e];
+                if (y_act) {
+                    const float zv = z[(32 * rt + rr) * LDZ + dcol];
+                    v = fmaf(zv, c_s, c_t) > 0.f ? v : 0.f;
+                    if (do_part) {
+                        s_a += v;
+                        s_b = fmaf(v, (zv - c_m) * c_i, s_b);
+                    }
+                }
+                a.out[(size_t)(trow0 + rr) * CY + dcol] = v;
+            }
+        }
+        if (more) write_lds(buf ^ 1, nxt);
+        __syncthreads();
+        buf ^= 1;
+        cur = nxt;
+        live = more;
+    }
+
+    // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
+    if (w_role) {
+        float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
+#pragma unroll
+        for (int i = 0; i < TXW; ++i)
+#pragma unroll
+            for (int j = 0; j < TYW; ++j) {
+                const int cy = 32 * (ty0 + j) + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int cx = 32 * (tx0 + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    dst[(size_t)cx * CY + cy] = acc_w[i][j][e];
+                }
+            }
+    }
+    float *red = sG;                      // everything staged has been consumed (barrier at the loop's end)
+    if (a.dbpart) {
+        *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        __syncthreads();
+        if (tid < CX) {
+            float s = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < SX; ++gi) s += red[gi * CX + tid];
+            a.dbpart[(size_t)blockIdx.x * CX + tid] = s;
+        }
+        __syncthreads();
+    }
+    if (do_part) {
+        // D wave (rt, dty): column dcol, two half-waves
+        const float oa = __shfl_xor(s_a, 32), ob = __shfl_xor(s_b, 32);
+        if (!w_role && h == 0) {
+            red[(rt * CY + dcol) * 2 + 0] = s_a + oa;
+            red[(rt * CY + dcol) * 2 + 1] = s_b + ob;
+        }
+        __syncthreads();
+        if (tid < CY) {
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int t = 0; t < ROWS / 32; ++t) {
+                sa += red[(t * CY + tid) * 2 + 0];
+                sb += red[(t * CY + tid) * 2 + 1];
+            }
+            a.part_a[(size_t)blockIdx.x * CY + tid] = sa;
+            a.part_b[(size_t)blockIdx.x * CY + tid] = sb;
+        }
+    }
+}
+
+int pw_bwd_blocks(int Q, int n_slots, int max_rows)
+{
+    // one workgroup per CU (8 waves, > 80 KB of LDS): as many as there are CUs, split evenly over the slots
+    const int cus = 256;
+    int bps = cus / n_slots;
+    if (bps < 1) bps = 1;
+    const int per_slot = (Q + n_slots - 1) / n_slots;
+    const int items = per_slot * ((max_rows + FB_ITEM_ROWS - 1) / FB_ITEM_ROWS);
+    return bps < items ? bps : (items > 0 ? items : 1);
+}
+
+bool pw_bwd_supported(int cx, int cy) { return (cx == 128 && (cy == 128 || cy == 64)) || (cx == 64 && cy == 64); }
+
+template <int CX, int CY, int ROWS>
+static int launch_fused(const PwBwd &a, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)(2 * ROWS * (CX + 4) + 2 * ROWS * (CY + 4) + CY * (CX + 4)) * sizeof(float);
+    static bool attr_set = false;
+    auto kern = pw_bwd_kernel<CX, CY, ROWS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_fused: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    char name[64];
+    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s", CX, CY, a.g.act ? "+gram" : "");
+    const double rows = (double)a.rows_hint;
+    const bool same = a.g.act && a.g.z == a.prev.z;
+    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * ((a.g.dy ? CX : 0) + ((a.g.P1 || a.g.act) ? CX : 0) + (same ? 0 : CY) + CY + (a.add ? CY : 0)), st);
+    hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(FB_THREADS), lds, st, a);
+    return check_launch("pw_bwd_kernel");
+}
+
+int pw_bwd_fused(const PwBwd &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.W && a.out && a.dWpart && a.win_off && a.prev.z, "pw_bwd_fused: null pointer");
+    AMPNET_REQUIRE(a.g.dy || a.g.act, "pw_bwd_fused: dense or activation operand only");
+    AMPNET_REQUIRE(!(a.g.P1 || a.g.act) || (a.g.P2 && a.g.P3 && a.g.z), "pw_bwd_fused: BatchNorm constants incomplete");
+    AMPNET_REQUIRE(a.prev.drop_p == 0.f, "pw_bwd_fused: dropout layers go through pw_wgrad / pw_dgrad");
+    AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.s), "pw_bwd_fused: partial sums need the previous layer's BatchNorm");
+    AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
+    AMPNET_REQUIRE(a.prev.C == 0 || pw_bwd_supported(a.g.C, a.prev.C), "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
+    if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);
+    if (a.g.C == 128 && a.prev.C == 64) return launch_fused<128, 64, 64>(a, st);
+    if (a.g.C == 64 && a.prev.C == 64) return launch_fused<64, 64, 64>(a, st);
+    return fail(AMPNET_E_ARG, "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
+}
+
+}  // namespace ampnet
