@@ -22,14 +22,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FB_THREADS = 512;
 constexpr int FB_ITEM_ROWS = 256;      // granularity of the work split inside a slot
 
-template <int CX, int CY, int ROWS>
+// GRAM: X operand = relu(z * P2 + P3) of the SAME tensor as z_{l-1} (pooled layers); otherwise dense dy with BatchNorm
+// constants.  YACT: the layer's input is relu(bn(z_{l-1})) (mask + sums), else z_{l-1} itself.  ADD: extra addend.
+// The modes are compile-time so that the prefetch loads sit in one basic block (no conservative vmcnt(0) between them).
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD>
 __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 {
     constexpr int LDG = CX + 4, LDZ = CY + 4;
     constexpr int TXN = CX / 32, TYN = CY / 32;
     constexpr int WXN = (TXN == 4 && TYN == 2) ? 4 : 2, WYN = 4 / WXN;
     constexpr int TXW = TXN / WXN, TYW = TYN / WYN;
-    constexpr int QX = CX / 4, QY = CY / 4, SX = FB_THREADS / QX, SY = FB_THREADS / QY;
+    constexpr int FB_STAGE = 256;                   // the four W waves stage; the D waves only compute and store, so
+                                                    // they never wait on a load behind their own pending stores
+    constexpr int QX = CX / 4, QY = CY / 4, SX = FB_STAGE / QX, SY = FB_STAGE / QY;
     constexpr int NIX = ROWS / SX, NIY = ROWS / SY;
     static_assert((ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
     static_assert(NIX >= 1 && NIY >= 1, "staging shape");
@@ -40,10 +45,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
-    const bool x_act = a.g.act != 0;
-    const bool has_bn = a.g.P1 != nullptr && !x_act;
-    const bool same = x_act && a.g.z == a.prev.z;           // Gram form: one tensor feeds both tiles
-    const bool y_act = a.prev.s != nullptr;
+    constexpr bool x_act = GRAM, has_bn = !GRAM, same = GRAM, y_act = YACT;
 
     // ---- work split: items = (window of this slot, chunk of FB_ITEM_ROWS rows), contiguous share per workgroup ----
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             for (int i = 0; i < 4; ++i) sWt[(4 * j4 + i) * LDG + k] = v[i];
         }
     }
-    const int cqx = tid % QX, rsx = tid / QX, cqy = tid % QY, rsy = tid / QY;
+    const int stid = tid & (FB_STAGE - 1);
+    const int cqx = stid % QX, rsx = stid / QX, cqy = stid % QY, rsy = stid / QY;
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
     if (has_bn) p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
     if (has_bn || x_act) {
@@ -173,15 +176,18 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 
     Pos cur, nxt;
     bool live = open_item(item_begin, cur);
-    if (live) load_regs(cur);
+    if (live && w_role) load_regs(cur);
     __syncthreads();                     // sWt staged
-    if (live) write_lds(0, cur);
+    if (live && w_role) write_lds(0, cur);
     __syncthreads();
     int buf = 0;
+    // every constant loaded above has landed before the loop: inside it, a wait on them would also wait for the
+    // D waves' own stores (loads and stores share vmcnt on gfx9-family parts)
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
     while (live) {
         nxt = cur;
         const bool more = advance(nxt);
-        if (more) load_regs(nxt);
+        if (more && w_role) load_regs(nxt);
         const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
         if (w_role) {
 #pragma unroll 4
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             const int valid = min(ROWS, cur.row_end - cur.row0) - 32 * rt;       // rows of this tile that exist (may be <= 0)
             const int trow0 = cur.row0 + 32 * rt;
             float addv[16];
-            if (a.add) {
+            if (ADD) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -230,24 +236,29 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], w1[i], acc1, 0, 0, 0);
                 }
             }
+            // epilogue: the sixteen z_{l-1} values of the lane come from LDS in one batch (rows past the block's end hold
+            // finite filler), everything else is predicated -- no load sits between two stores
+            float zv[16];
+            if (YACT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zv[e] = z[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (rr >= valid) continue;
+                const bool ok = rr < valid;
                 float v = acc0[e] + acc1[e] + c_b;
-                if (a.add) v += addv[e];
-                if (y_act) {
-                    const float zv = z[(32 * rt + rr) * LDZ + dcol];
-                    v = fmaf(zv, c_s, c_t) > 0.f ? v : 0.f;
-                    if (do_part) {
-                        s_a += v;
-                        s_b = fmaf(v, (zv - c_m) * c_i, s_b);
-                    }
+                if (ADD) v += addv[e];
+                if (YACT) {
+                    v = fmaf(zv[e], c_s, c_t) > 0.f ? v : 0.f;
+                    const float vs = ok ? v : 0.f;
+                    s_a += vs;
+                    s_b = fmaf(vs, (zv[e] - c_m) * c_i, s_b);
                 }
-                a.out[(size_t)(trow0 + rr) * CY + dcol] = v;
+                if (ok) a.out[(size_t)(trow0 + rr) * CY + dcol] = v;
             }
         }
-        if (more) write_lds(buf ^ 1, nxt);
+        if (more && w_role) write_lds(buf ^ 1, nxt);
         __syncthreads();
         buf ^= 1;
         cur = nxt;
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     }
     float *red = sG;                      // everything staged has been consumed (barrier at the loop's end)
     if (a.dbpart) {
-        *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        if (w_role) *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
         __syncthreads();
         if (tid < CX) {
             float s = 0.f;
@@ -315,12 +326,12 @@ int pw_bwd_blocks(int Q, int n_slots, int max_rows)
 
 bool pw_bwd_supported(int cx, int cy) { return (cx == 128 && (cy == 128 || cy == 64)) || (cx == 64 && cy == 64); }
 
-template <int CX, int CY, int ROWS>
-static int launch_fused(const PwBwd &a, hipStream_t st)
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD>
+static int launch_fused_x(const PwBwd &a, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(2 * ROWS * (CX + 4) + 2 * ROWS * (CY + 4) + CY * (CX + 4)) * sizeof(float);
     static bool attr_set = false;
-    auto kern = pw_bwd_kernel<CX, CY, ROWS>;
+    auto kern = pw_bwd_kernel<CX, CY, ROWS, GRAM, YACT, ADD>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_fused: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -335,11 +346,28 @@ static int launch_fused(const PwBwd &a, hipStream_t st)
     return check_launch("pw_bwd_kernel");
 }
 
+template <int CX, int CY, int ROWS>
+static int launch_fused(const PwBwd &a, hipStream_t st)
+{
+    const bool gram = a.g.act != 0, yact = a.prev.s != nullptr, add = a.add != nullptr;
+    if (gram) {
+        if (CX != CY || !yact || add) return fail(AMPNET_E_ARG, "pw_bwd_fused: Gram form needs CX == CY, an activated input and no addend");
+        if constexpr (CX == CY) return launch_fused_x<CX, CY, ROWS, true, true, false>(a, st);
+    }
+    if (add) {
+        // only the 64 x 64 layers have an addend (conv_3: the head's d_local, feature T-Net conv_1: the bmm path)
+        if constexpr (CX == 64 && CY == 64)
+            return yact ? launch_fused_x<CX, CY, ROWS, false, true, true>(a, st) : launch_fused_x<CX, CY, ROWS, false, false, true>(a, st);
+        return fail(AMPNET_E_ARG, "pw_bwd_fused: addend only built for 64 x 64");
+    }
+    return yact ? launch_fused_x<CX, CY, ROWS, false, true, false>(a, st) : launch_fused_x<CX, CY, ROWS, false, false, false>(a, st);
+}
+
 int pw_bwd_fused(const PwBwd &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.W && a.out && a.dWpart && a.win_off && a.prev.z, "pw_bwd_fused: null pointer");
-    AMPNET_REQUIRE(a.g.dy || a.g.act, "pw_bwd_fused: dense or activation operand only");
-    AMPNET_REQUIRE(!(a.g.P1 || a.g.act) || (a.g.P2 && a.g.P3 && a.g.z), "pw_bwd_fused: BatchNorm constants incomplete");
+    AMPNET_REQUIRE(a.g.act ? a.g.z == a.prev.z : (a.g.dy && a.g.P1), "pw_bwd_fused: dense gradient with BatchNorm constants, or the Gram form of one tensor");
+    AMPNET_REQUIRE(a.g.P2 && a.g.P3 && a.g.z, "pw_bwd_fused: BatchNorm constants incomplete");
     AMPNET_REQUIRE(a.prev.drop_p == 0.f, "pw_bwd_fused: dropout layers go through pw_wgrad / pw_dgrad");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.s), "pw_bwd_fused: partial sums need the previous layer's BatchNorm");
     AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
