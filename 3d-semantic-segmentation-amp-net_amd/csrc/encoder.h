@@ -38,8 +38,8 @@ struct EncWs {
     int *arg_t, *arg_f, *arg_c;        // [Q, 256] row index of the pooled extreme
     float *zext_t, *zext_f, *zext_c;   // [Q, 256] its pre-BatchNorm value (all the backward needs of the 256-channel layers)
     int *fc_off;                       // [n_slots + 1]
-    float *part_sum, *part_sq, *part_max, *part_min;   // [Q * chunks, 256]
-    int *part_amax, *part_amin;
+    float *part_sum, *part_sq, *part_max;   // [Q * chunks, 256]
+    int *part_amax;
     BnSlot bn[BN_ENC_COUNT];
     size_t bytes;
 };

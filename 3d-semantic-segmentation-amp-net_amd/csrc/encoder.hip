@@ -95,9 +95,7 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.part_sum = c.take<float>(np_bwd);
     ws.part_sq = c.take<float>(np_bwd);
     ws.part_max = c.take<float>(np);
-    ws.part_min = c.take<float>(np);
     ws.part_amax = c.take<int>(np);
-    ws.part_amin = c.take<int>(np);
     for (int i = 0; i < BN_ENC_COUNT; ++i) {
         const size_t n = (size_t)s.n_slots * kBnC[i];
         ws.bn[i].C = kBnC[i];
@@ -142,7 +140,7 @@ struct EncRun {
     }
 
     // point layer on the real windows
-    PwGemm point_layer(const float *A, int cin, const float *W, int cout, int pro_bn, float *Z, bool stats, bool pool) const
+    PwGemm point_layer(const float *A, int cin, const float *W, int cout, int pro_bn, float *Z, bool stats, bool pool, int pool_bn = -1) const
     {
         PwGemm g;
         g.A = A; g.lda = cin; g.cin = cin;
@@ -151,7 +149,7 @@ struct EncRun {
         g.n_slots = s.train ? s.n_slots : 1;
         g.Z = Z; g.ldz = cout; g.cout = cout;
         if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        if (pool) { g.part_max = ws.part_max; g.part_min = ws.part_min; g.part_amax = ws.part_amax; g.part_amin = ws.part_amin; }
+        if (pool) { g.part_max = ws.part_max; g.part_amax = ws.part_amax; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
         return g;
     }
@@ -187,7 +185,7 @@ struct EncRun {
     int pool(int bn, float *pooled, int *arg, float *zext, bool slot_major) const
     {
         PoolFinalize p;
-        p.part_max = ws.part_max; p.part_min = ws.part_min; p.part_amax = ws.part_amax; p.part_amin = ws.part_amin;
+        p.part_max = ws.part_max; p.part_amax = ws.part_amax;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
         p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
         p.out_slot_major = (slot_major && s.train) ? 1 : 0;
@@ -219,7 +217,7 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
     TRY(e.finalize(bn0 + 0, false));
     TRY(pw_gemm(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), e.st));
     TRY(e.finalize(bn0 + 1, false));
-    TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true), e.st));
+    TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true, bn0 + 2), e.st));
     TRY(e.finalize(bn0 + 2, false));
     TRY(e.pool(bn0 + 2, pooled, arg, zext, true));
     // FC head on [Q, 256]
@@ -301,7 +299,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(e.finalize(BN_C4, false));
     TRY(pw_gemm(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), e.st));
     TRY(e.finalize(BN_C5, false));
-    TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true), e.st));
+    TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true, BN_C6), e.st));
     TRY(e.finalize(BN_C6, false));
     TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, e.ws.zext_c, false));
 

@@ -34,10 +34,9 @@ struct PwGemm {
     int cout = 0;
     float *part_sum = nullptr;     // [Q * chunks, cout] or nullptr: per-chunk MEAN of each output column
     float *part_sq = nullptr;      //                               per-chunk sum of squared deviations from it
-    float *part_max = nullptr;     // [Q * chunks, cout] or nullptr
-    float *part_min = nullptr;
-    int *part_amax = nullptr;
-    int *part_amin = nullptr;
+    float *part_max = nullptr;     // [Q * chunks, cout] or nullptr: per-chunk extreme of each column (max if gamma >= 0 else min)
+    int *part_amax = nullptr;      //                               and the row it sits in
+    const float *pool_gamma = nullptr;   // [cout] BatchNorm weight of THIS layer: its sign picks max or min; nullptr = max
     const int *win_off = nullptr;  // [Q + 1] device
     int Q = 0;
     int chunk_rows = 512;
@@ -96,10 +95,11 @@ struct BnRunItem {
 int bn_running_update(const BnRunItem *items_host, int n_items, float momentum, hipStream_t st);
 
 // MaxPool1d over each window after BatchNorm + ReLU:
-//   pooled[orow(q), c] = relu(scale * (scale >= 0 ? max : min) + shift), arg[q, c] = row index of that extreme
+//   pooled[orow(q), c] = relu(scale * extreme + shift), extreme = max for scale >= 0 else min (pw_gemm tracked the one
+//   sign(gamma) = sign(scale) asks for), arg[q, c] = row index of that extreme
 struct PoolFinalize {
-    const float *part_max = nullptr, *part_min = nullptr;
-    const int *part_amax = nullptr, *part_amin = nullptr;
+    const float *part_max = nullptr;
+    const int *part_amax = nullptr;
     const float *scale = nullptr, *shift = nullptr;   // [n_slots, C]
     int Q = 0, chunks = 1, n_slots = 1, C = 0;
     int out_slot_major = 0;       // orow(q) = (q % n_slots) * (Q / n_slots) + q / n_slots, else q

@@ -31,7 +31,10 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
     return slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
 }
 
-template <int CIN, int NT>
+// PRO: prologue on the A operand -- 0 none, 1 relu(a * scale + shift), 2 the same then dropout.  POOL: track the per-channel
+// extreme (+ its row) instead of / besides storing.  Both are compile-time so that the K loop and the epilogue are straight-line
+// code: LDS reads get scheduled ahead of the MFMAs that use them and no branch sits between two epilogue elements.
+template <int CIN, int NT, int PRO, bool POOL>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
     constexpr int CB = 32 * NT;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 sW[j * LDW + k] = (cb0 + j < a.cout) ? Wg[(size_t)k * a.cout + cb0 + j] : 0.f;
             }
         }
-        if (a.pro_scale) {
+        if (PRO) {
             for (int e = tid; e < CIN; e += PW_NW * 64) {
                 sPro[e] = a.pro_scale[(size_t)slot * CIN + e];
                 sPro[CIN + e] = a.pro_shift[(size_t)slot * CIN + e];
@@ -84,36 +87,32 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     }
     __syncthreads();
 
-    const bool has_pro = a.pro_scale != nullptr;
-    const bool has_drop = a.drop_p > 0.f;
     const uint32_t dthr = drop_threshold(a.drop_p);
     const uint32_t dbase = a.drop_seed;
-    const float dscale = has_drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const float dscale = PRO == 2 ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const bool do_stats = a.part_sum != nullptr;
-    const bool do_pool = a.part_max != nullptr;
+    const bool do_store = a.Z != nullptr;
 
     // BatchNorm statistics are accumulated as sums of (v - z0) and (v - z0)^2 with z0 = the wave's first
     // row: E[z^2] - mean^2 in fp32 loses everything when a channel's spread is small against its mean
     // (the T-Net FC layers normalise over only B rows of near-identical pooled features).
-    float s_sum[NT], s_sq[NT], s_max[NT], s_min[NT], s_z0[NT];
-    int s_amax[NT], s_amin[NT];
+    // MaxPool: BatchNorm + ReLU are monotone per channel with the direction of sign(gamma) (scale = gamma * invstd), so one
+    // signed extreme per channel is enough: ext = max over rows of sgn * v.
+    float s_sum[NT], s_sq[NT], s_ext[NT], s_z0[NT], sgn[NT], bias_v[NT];
+    int s_arg[NT];
     int s_cnt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        const int col = cb0 + 32 * t + r;
         s_z0[t] = 0.f;
         s_sum[t] = 0.f;
         s_sq[t] = 0.f;
-        s_max[t] = -__builtin_inff();
-        s_min[t] = __builtin_inff();
-        s_amax[t] = -1;
-        s_amin[t] = -1;
-    }
-    float bias_v[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = cb0 + 32 * t + r;
+        s_ext[t] = -__builtin_inff();
+        s_arg[t] = -1;
+        sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
         bias_v[t] = (a.bias && col < a.cout) ? a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the constants above have landed (see pw_bwd_fused.hip)
 
     const int ntiles = (nrows + 31) / 32;
     // A fragments: blocks of 4 j (= 32 k = one 128-byte line per row), the next block prefetched in registers
@@ -162,12 +161,12 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             for (int j = 0; j < 4; ++j) {
                 const int k0 = 32 * kb + 8 * j + 4 * h;
                 f32x4 av = a_cur[j];
-                if (has_pro) {
+                if (PRO) {
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
                     const f32x4 sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) av[i] = fmaxf(fmaf(av[i], sc[i], sh[i]), 0.f);
-                    if (has_drop) {
+                    if (PRO == 2) {
                         const uint32_t e0 = (uint32_t)arow * (uint32_t)CIN + (uint32_t)k0;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) av[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? av[i] * dscale : 0.f;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
         }
 
-        // ---- epilogue: lane = output channel, registers = 16 rows ----
+        // ---- epilogue: lane = output channel, registers = 16 rows; predicated, no branch between elements ----
         if (do_stats) {
             if (tile == wave) {
 #pragma unroll
@@ -197,62 +196,53 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         for (int t = 0; t < NT; ++t) {
             const int col = cb0 + 32 * t + r;
             const bool cok = col < a.cout;
+            float *zp = a.Z + (size_t)row0 * a.ldz + col;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const float v = acc[t][e] + bias_v[t];
                 const bool ok = rr < valid;
-                if (a.Z && ok && cok) a.Z[(size_t)(row0 + rr) * a.ldz + col] = v;
-                if (do_stats && ok) {
-                    const float d = v - s_z0[t];
+                if (do_store && ok && cok) zp[(size_t)rr * a.ldz] = v;
+                if (do_stats) {
+                    const float d = ok ? v - s_z0[t] : 0.f;
                     s_sum[t] += d;
                     s_sq[t] = fmaf(d, d, s_sq[t]);
                 }
-                if (do_pool && ok) {
-                    if (v > s_max[t]) {
-                        s_max[t] = v;
-                        s_amax[t] = row0 + rr;
-                    }
-                    if (v < s_min[t]) {
-                        s_min[t] = v;
-                        s_amin[t] = row0 + rr;
-                    }
+                if (POOL) {
+                    const float vs = ok ? v * sgn[t] : -__builtin_inff();
+                    const bool gt = vs > s_ext[t];               // strict: rows ascend, the first extreme wins
+                    s_ext[t] = gt ? vs : s_ext[t];
+                    s_arg[t] = gt ? row0 + rr : s_arg[t];
                 }
             }
         }
     }
 
-    if (!do_stats && !do_pool) return;
+    if (!do_stats && !POOL) return;
 
     // ---- combine the two half-waves, then the waves (LDS scratch reuses the weight tile) ----
     __syncthreads();
-    float *red_f = smem;                                           // [PW_NW][CB][5]: S1, S2, max, min, z0
-    int *red_i = reinterpret_cast<int *>(smem + PW_NW * CB * 5);   // [PW_NW][CB][2]: amax, amin
-    int *red_n = red_i + PW_NW * CB * 2;                           // [PW_NW] rows seen by the wave
+    float *red_f = smem;                                           // [PW_NW][CB][4]: S1, S2, ext, z0
+    int *red_i = reinterpret_cast<int *>(smem + PW_NW * CB * 4);   // [PW_NW][CB]: arg
+    int *red_n = red_i + PW_NW * CB;                               // [PW_NW] rows seen by the wave
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float o_sum = __shfl_xor(s_sum[t], 32), o_sq = __shfl_xor(s_sq[t], 32);
-        const float o_max = __shfl_xor(s_max[t], 32), o_min = __shfl_xor(s_min[t], 32);
-        const int o_amax = __shfl_xor(s_amax[t], 32), o_amin = __shfl_xor(s_amin[t], 32);
-        float f_max = s_max[t], f_min = s_min[t];
-        int f_amax = s_amax[t], f_amin = s_amin[t];
-        if (o_max > f_max || (o_max == f_max && (unsigned)o_amax < (unsigned)f_amax)) {
-            f_max = o_max;
-            f_amax = o_amax;
-        }
-        if (o_min < f_min || (o_min == f_min && (unsigned)o_amin < (unsigned)f_amin)) {
-            f_min = o_min;
-            f_amin = o_amin;
+        const float o_ext = __shfl_xor(s_ext[t], 32);
+        const int o_arg = __shfl_xor(s_arg[t], 32);
+        float f_ext = s_ext[t];
+        int f_arg = s_arg[t];
+        if (o_ext > f_ext || (o_ext == f_ext && (unsigned)o_arg < (unsigned)f_arg)) {
+            f_ext = o_ext;
+            f_arg = o_arg;
         }
         if (h == 0) {
             const int c = 32 * t + r;
-            red_f[(wave * CB + c) * 5 + 0] = s_sum[t] + o_sum;
-            red_f[(wave * CB + c) * 5 + 1] = s_sq[t] + o_sq;
-            red_f[(wave * CB + c) * 5 + 2] = f_max;
-            red_f[(wave * CB + c) * 5 + 3] = f_min;
-            red_f[(wave * CB + c) * 5 + 4] = s_z0[t];
-            red_i[(wave * CB + c) * 2 + 0] = f_amax;
-            red_i[(wave * CB + c) * 2 + 1] = f_amin;
+            red_f[(wave * CB + c) * 4 + 0] = s_sum[t] + o_sum;
+            red_f[(wave * CB + c) * 4 + 1] = s_sq[t] + o_sq;
+            red_f[(wave * CB + c) * 4 + 2] = f_ext;
+            red_f[(wave * CB + c) * 4 + 3] = s_z0[t];
+            red_i[wave * CB + c] = f_arg;
         }
     }
     if (lane == 0) red_n[wave] = s_cnt;
@@ -261,29 +251,25 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         const int col = cb0 + c;
         if (col >= a.cout) continue;
         double n = 0.0, mean = 0.0, m2 = 0.0;                      // Chan's pairwise merge, fixed wave order
-        float mx = -__builtin_inff(), mn = __builtin_inff();
-        int amx = -1, amn = -1;
+        float ext = -__builtin_inff();
+        int arg = -1;
 #pragma unroll
         for (int w = 0; w < PW_NW; ++w) {
             const double nw = (double)red_n[w];
             if (do_stats && nw > 0.0) {
-                const double s1 = red_f[(w * CB + c) * 5 + 0], s2 = red_f[(w * CB + c) * 5 + 1];
-                const double mw = (double)red_f[(w * CB + c) * 5 + 4] + s1 / nw;
+                const double s1 = red_f[(w * CB + c) * 4 + 0], s2 = red_f[(w * CB + c) * 4 + 1];
+                const double mw = (double)red_f[(w * CB + c) * 4 + 3] + s1 / nw;
                 const double m2w = s2 - s1 * s1 / nw;
                 const double nn = n + nw, delta = mw - mean;
                 mean += delta * nw / nn;
                 m2 += m2w + delta * delta * n * nw / nn;
                 n = nn;
             }
-            const float vmx = red_f[(w * CB + c) * 5 + 2], vmn = red_f[(w * CB + c) * 5 + 3];
-            const int imx = red_i[(w * CB + c) * 2 + 0], imn = red_i[(w * CB + c) * 2 + 1];
-            if (vmx > mx || (vmx == mx && (unsigned)imx < (unsigned)amx)) {
-                mx = vmx;
-                amx = imx;
-            }
-            if (vmn < mn || (vmn == mn && (unsigned)imn < (unsigned)amn)) {
-                mn = vmn;
-                amn = imn;
+            const float ve = red_f[(w * CB + c) * 4 + 2];
+            const int ie = red_i[w * CB + c];
+            if (ve > ext || (ve == ext && (unsigned)ie < (unsigned)arg)) {
+                ext = ve;
+                arg = ie;
             }
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
@@ -291,24 +277,23 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             a.part_sum[o] = (float)mean;            // chunk mean
             a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
-        if (do_pool) {
-            a.part_max[o] = mx;
-            a.part_min[o] = mn;
-            a.part_amax[o] = amx;
-            a.part_amin[o] = amn;
+        if (POOL) {
+            const float sg = (a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
+            a.part_max[o] = ext * sg;               // the extreme itself (max for gamma >= 0, min otherwise)
+            a.part_amax[o] = arg;
         }
     }
 }
 
-template <int CIN, int NT>
-static int launch_pw(const PwGemm &a, hipStream_t st)
+template <int CIN, int NT, int PRO, bool POOL>
+static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
-    constexpr size_t lds_red = (size_t)(PW_NW * CB * 7 + PW_NW) * sizeof(float);
+    constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
     constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
     static bool attr_set = false;
-    auto kern = pw_gemm_kernel<CIN, NT>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL>;
     if (!attr_set) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -325,6 +310,25 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
     return check_launch("pw_gemm_kernel");
 }
 
+// the (prologue, pool) variants each shape is actually used with; anything else is an argument error
+template <int CIN, int NT>
+static int launch_pw(const PwGemm &a, hipStream_t st)
+{
+    const int pro = a.pro_scale ? (a.drop_p > 0.f ? 2 : 1) : 0;
+    const bool pool = a.part_max != nullptr;
+    if (pool) {
+        if constexpr (CIN == 128 && NT == 4) {
+            if (pro == 1) return launch_pw_x<CIN, NT, 1, true>(a, st);
+        }
+        return fail(AMPNET_E_ARG, "pw_gemm: max-pool epilogue is built for cin 128, >64 columns, BatchNorm+ReLU prologue");
+    }
+    if (pro == 2) {
+        if constexpr (CIN == 128 && NT == 2) return launch_pw_x<CIN, NT, 2, false>(a, st);
+        return fail(AMPNET_E_ARG, "pw_gemm: dropout prologue is built for cin 128, 33..64 columns");
+    }
+    return pro ? launch_pw_x<CIN, NT, 1, false>(a, st) : launch_pw_x<CIN, NT, 0, false>(a, st);
+}
+
 int pw_gemm(const PwGemm &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.A && a.W && a.win_off, "pw_gemm: null pointer");
@@ -332,7 +336,7 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_gemm: part_sum/part_sq must come together");
-    AMPNET_REQUIRE(!a.part_max || (a.part_min && a.part_amax && a.part_amin), "pw_gemm: pool partials incomplete");
+    AMPNET_REQUIRE(!a.part_max || a.part_amax, "pw_gemm: pool partials incomplete");
     const int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);
     switch (a.cin) {
     case 64:

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
         const bool use_max = sc >= 0.f;
         for (int ch = 0; ch < a.chunks; ++ch) {
             const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
-            const float v = use_max ? a.part_max[o] : a.part_min[o];
-            const int i = use_max ? a.part_amax[o] : a.part_amin[o];
+            const float v = a.part_max[o];
+            const int i = a.part_amax[o];
             if (i < 0) continue;
             if (arg < 0 || (use_max ? v > best : v < best)) {     // chunks ascend in row order: first extreme wins
                 best = v;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
 
 int pool_finalize(const PoolFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_max && a.part_min && a.part_amax && a.part_amin && a.scale && a.shift && a.pooled, "pool_finalize: null pointer");
+    AMPNET_REQUIRE(a.part_max && a.part_amax && a.scale && a.shift && a.pooled, "pool_finalize: null pointer");
     AMPNET_REQUIRE(!a.out_slot_major || a.Q % a.n_slots == 0, "pool_finalize: Q %% n_slots != 0");
     hipLaunchKernelGGL(pool_finalize_kernel, dim3(a.Q), dim3(256), 0, st, a);
     return check_launch("pool_finalize_kernel");
