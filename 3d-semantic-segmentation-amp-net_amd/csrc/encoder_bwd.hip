@@ -56,8 +56,9 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.dyB = c.take<float>(R * 128);
     w.d_local = c.take<float>(R * 64);
     w.d_h = c.take<float>(R * 64);
-    w.wpart = c.take<float>(Q * (size_t)wg_chunks(s) * 256 * 128);
-    w.dbpart = c.take<float>(Q * (size_t)wg_chunks(s) * 256);
+    // + 320 + n_slots: the fused backward writes one partial per workgroup (<= 256 + n_slots of them)
+    w.wpart = c.take<float>((Q * (size_t)wg_chunks(s) + 320 + s.n_slots) * 256 * 128);
+    w.dbpart = c.take<float>((Q * (size_t)wg_chunks(s) + 320 + s.n_slots) * 256);
     w.dpm = c.take<float>(Q * 256);
     w.a1 = c.take<float>(Q * 256);
     w.a2 = c.take<float>(Q * 128);

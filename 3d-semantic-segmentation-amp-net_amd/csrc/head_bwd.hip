@@ -4,13 +4,14 @@
 //   head_out_bwd (conv_4, dropout, bn_3 ReLU mask)  -> pw_wgrad/pw_dgrad conv_3 -> pw_wgrad/pw_dgrad conv_2
 //   (the per-window column sums of conv_2's gradient ARE the gradient of the per-window token bias)
 //   -> small SGEMMs for the token half of conv_2, out_proj, in_proj -> attention_core_bwd -> posenc backward.
+#include <cstdlib>
 #include "bwd_misc.h"
 #include "head.h"
 
 namespace ampnet {
 namespace {
 
-constexpr int HB_ROWS = 128;
+constexpr int HB_WAVES = 4, HB_WROWS = 256, HB_ROWS = HB_WAVES * HB_WROWS;   // rows per wave / per workgroup
 
 struct HeadOutBwd {
     const float *dlogits;      // [B, C, P]
@@ -25,94 +26,87 @@ struct HeadOutBwd {
     float *dWpart;             // [blocks, C * 64 + C]
 };
 
-__global__ __launch_bounds__(HB_ROWS) void head_out_bwd_kernel(HeadOutBwd a)
+// conv_4 backward + dropout + bn_3/ReLU mask, no LDS in the row loop: lane = channel k of the 64, a wave walks its rows.
+// Per row the lane loads z3[row][k] (one 256-byte line per wave), rebuilds a3 = dropout(relu(bn_3(z3))), forms
+// da3[k] = sum_c dlogits[row][c] W4[c][k] from five wave-uniform gradients (loaded 64 rows at a time with lane = row and
+// broadcast by readlane), masks it and accumulates dW4[c][k], sum dy3, sum dy3 * zhat in registers.
+__global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd a)
 {
-    __shared__ float sA[HB_ROWS][65];      // a3 = dropout(relu(bn_3(z3))), later dy3
-    __shared__ float sZ[HB_ROWS][65];      // zhat of z3
-    __shared__ float sD[HB_ROWS][HEAD_MAX_CLASSES];
-    __shared__ float sW[HEAD_MAX_CLASSES][64], sSc[64], sSh[64], sMe[64], sIs[64];
-    const int tid = threadIdx.x, row0 = blockIdx.x * HB_ROWS;
-    const int n = min(HB_ROWS, a.R - row0);
-    for (int e = tid; e < a.C * 64; e += HB_ROWS) sW[e / 64][e % 64] = a.W[e];
-    if (tid < 64) {
-        sSc[tid] = a.scale[tid];
-        sSh[tid] = a.shift[tid];
-        sMe[tid] = a.mean[tid];
-        sIs[tid] = a.invstd[tid];
+    __shared__ float red[HB_WAVES][HEAD_MAX_CLASSES + 3][64];
+    const int tid = threadIdx.x, k = tid & 63, wave = tid >> 6;
+    const float sc = a.scale[k], sh = a.shift[k], me = a.mean[k], is = a.invstd[k];
+    float w[HEAD_MAX_CLASSES], dW[HEAD_MAX_CLASSES], db[HEAD_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_CLASSES; ++c) {
+        w[c] = c < a.C ? a.W[c * 64 + k] : 0.f;
+        dW[c] = 0.f;
+        db[c] = 0.f;
     }
-    __syncthreads();
+    float pa = 0.f, pb = 0.f;
+    const bool has_drop = a.drop_p > 0.f;
     const uint32_t thr = drop_threshold(a.drop_p);
-    const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-    for (int e0 = tid; e0 < HB_ROWS * 64; e0 += 8 * HB_ROWS) {
-      float tmp[8];
+    const float dscale = has_drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const int wrow0 = blockIdx.x * HB_ROWS + wave * HB_WROWS;
+    for (int r0 = wrow0; r0 < min(wrow0 + HB_WROWS, a.R); r0 += 64) {
+        // gradients of 64 rows: lane = row
+        float dreg[HEAD_MAX_CLASSES];
+        {
+            const int row = r0 + k;
+            const bool ok = row < a.R;
+            const int b = ok ? row / a.P : 0, p = ok ? row % a.P : 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {               // 8 independent loads in flight, then their uses
-          const int e = e0 + u * HB_ROWS;
-          tmp[u] = (e / 64) < n ? a.z3[(size_t)row0 * 64 + e] : 0.f;
-      }
+            for (int c = 0; c < HEAD_MAX_CLASSES; ++c) dreg[c] = (ok && c < a.C) ? a.dlogits[((size_t)b * a.C + c) * a.P + p] : 0.f;
+        }
+#pragma unroll 1
+        for (int i0 = 0; i0 < 64; i0 += 8) {
+            if (r0 + i0 >= a.R) break;
+            float zv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * HB_ROWS;
-        const int i = e / 64, k = e % 64;
-        float av = 0.f, zh = 0.f;
-        if (i < n) {
-            const float zv = tmp[u];
-            zh = (zv - sMe[k]) * sIs[k];
-            av = fmaxf(fmaf(zv, sSc[k], sSh[k]), 0.f);
-            if (a.drop_p > 0.f) av = (mix32(((uint32_t)(row0 + i) * 64u + (uint32_t)k) ^ a.drop_seed) >= thr) ? av * dscale : 0.f;
-        }
-        sA[i][k] = av;
-        sZ[i][k] = zh;
-      }
-    }
-    {
-        const int row = row0 + tid;
-        for (int c = 0; c < HEAD_MAX_CLASSES; ++c) {
-            float d = 0.f;
-            if (tid < n && c < a.C) d = a.dlogits[((size_t)(row / a.P) * a.C + c) * a.P + row % a.P];
-            sD[tid][c] = d;
-        }
-    }
-    __syncthreads();
-    // conv_4 weight / bias gradient partial of this block: (c, k) pairs over the block's rows
-    for (int e = tid; e < a.C * 64 + a.C; e += HB_ROWS) {
-        float s = 0.f;
-        if (e < a.C * 64) {
-            const int c = e / 64, k = e % 64;
-            for (int i = 0; i < n; ++i) s = fmaf(sD[i][c], sA[i][k], s);
-        } else {
-            const int c = e - a.C * 64;
-            for (int i = 0; i < n; ++i) s += sD[i][c];
-        }
-        a.dWpart[(size_t)blockIdx.x * (a.C * 64 + a.C) + e] = s;
-    }
-    __syncthreads();
-    // da3 = dlogits . W, masked -> dy3 (overwrites sA row by row: each thread owns its row)
-    if (tid < n) {
-        const int row = row0 + tid;
-        for (int k = 0; k < 64; ++k) {
-            float v = 0.f;
+            for (int u = 0; u < 8; ++u) zv[u] = a.z3[(size_t)min(r0 + i0 + u, a.R - 1) * 64 + k];
 #pragma unroll
-            for (int c = 0; c < HEAD_MAX_CLASSES; ++c)
-                if (c < a.C) v = fmaf(sD[tid][c], sW[c][k], v);
-            const bool live = sA[tid][k] > 0.f;       // relu > 0 and kept by dropout
-            if (a.drop_p > 0.f) v *= dscale;
-            (void)row;
-            sA[tid][k] = live ? v : 0.f;
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + i0 + u;
+                const bool valid = row < a.R;
+                float d[HEAD_MAX_CLASSES];
+#pragma unroll
+                for (int c = 0; c < HEAD_MAX_CLASSES; ++c)
+                    d[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dreg[c]), i0 + u));   // 0 for rows past the end
+                const float zh = (zv[u] - me) * is;
+                float av = fmaxf(fmaf(zv[u], sc, sh), 0.f);
+                if (has_drop) av = (mix32(((uint32_t)row * 64u + (uint32_t)k) ^ a.drop_seed) >= thr) ? av * dscale : 0.f;
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < HEAD_MAX_CLASSES; ++c) v = fmaf(d[c], w[c], v);
+                v *= dscale;
+                const float dy = av > 0.f ? v : 0.f;                  // relu > 0 and kept by dropout
+                if (valid) a.dy3[(size_t)row * 64 + k] = dy;
+#pragma unroll
+                for (int c = 0; c < HEAD_MAX_CLASSES; ++c) {
+                    dW[c] = fmaf(d[c], av, dW[c]);
+                    db[c] += d[c];
+                }
+                pa += dy;
+                pb = fmaf(dy, zh, pb);
+            }
         }
-    } else {
-        for (int k = 0; k < 64; ++k) sA[tid][k] = 0.f;
     }
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_CLASSES; ++c) red[wave][c][k] = dW[c];
+    red[wave][HEAD_MAX_CLASSES][k] = pa;
+    red[wave][HEAD_MAX_CLASSES + 1][k] = pb;
+    red[wave][HEAD_MAX_CLASSES + 2][k] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < HEAD_MAX_CLASSES; ++c)
+        if (k == c) red[wave][HEAD_MAX_CLASSES + 2][c] = db[c];       // every lane holds the same sums
     __syncthreads();
-    for (int e = tid; e < n * 64; e += HB_ROWS) a.dy3[(size_t)row0 * 64 + e] = sA[e / 64][e % 64];
-    if (tid < 64) {
-        float sa = 0.f, sb = 0.f;
-        for (int i = 0; i < n; ++i) {
-            sa += sA[i][tid];
-            sb = fmaf(sA[i][tid], sZ[i][tid], sb);
-        }
-        a.part_a[(size_t)blockIdx.x * 64 + tid] = sa;
-        a.part_b[(size_t)blockIdx.x * 64 + tid] = sb;
+    if (wave == 0) {
+        auto sum4 = [&](int j, int col) { return (red[0][j][col] + red[1][j][col]) + (red[2][j][col] + red[3][j][col]); };
+        float *dst = a.dWpart + (size_t)blockIdx.x * (a.C * 64 + a.C);
+        for (int c = 0; c < a.C; ++c) dst[c * 64 + k] = sum4(c, k);
+        if (k < a.C) dst[a.C * 64 + k] = sum4(HEAD_MAX_CLASSES + 2, k);
+        a.part_a[(size_t)blockIdx.x * 64 + k] = sum4(HEAD_MAX_CLASSES, k);
+        a.part_b[(size_t)blockIdx.x * 64 + k] = sum4(HEAD_MAX_CLASSES + 1, k);
     }
 }
 
@@ -233,11 +227,12 @@ void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
     w.dy3 = c.take<float>(R * 64);
     w.dy2 = c.take<float>(R * 128);
     const size_t wch = (size_t)cdiv(s.max_rows, 1024);
-    w.wpart = c.take<float>(Q * wch * 128 * 128);
-    w.dbpart = c.take<float>(Q * wch * 128);
+    // + 256: the fused backward writes one partial per workgroup (<= 256 of them) instead of one per (window, chunk)
+    w.wpart = c.take<float>((Q * wch + 256) * 128 * 128);
+    w.dbpart = c.take<float>((Q * wch + 256) * 128);
     w.dgb = c.take<float>(Q * 128);
     w.w4part = c.take<float>(blocks * (HEAD_MAX_CLASSES * 64 + HEAD_MAX_CLASSES));
-    const size_t np = (Q * (size_t)s.chunks > blocks ? Q * (size_t)s.chunks : blocks) * 128;
+    const size_t np = ((Q * (size_t)s.chunks > blocks ? Q * (size_t)s.chunks : blocks) + 256) * 128;
     w.part_a = c.take<float>(np);
     w.part_b = c.take<float>(np);
     const int Cs[2] = {128, 64};
@@ -309,7 +304,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
         o.W = P[HP_CONV4_W]; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
         o.R = R; o.P = R / B; o.C = C;
         o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
-        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(HB_ROWS), 0, st, o);
+        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
         TRY(check_launch("head_out_bwd_kernel"));
         TRY(reduce_windows(b.w4part, blocks, C * 64 + C, 1, C * 64, C * 64, G[HP_CONV4_W], C * 64, 0, st));
         TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, G[HP_CONV4_B], C, 0, st));
@@ -325,7 +320,27 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1];
     ActSrc a2;
     a2.z = f.z2; a2.C = 128; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
-    {
+    const char *fenv = getenv("AMPNET_FUSED_BWD");
+    const bool fused = !(fenv && fenv[0] == '0');
+    if (fused) {
+        // one pass over (dy3, z3, z2): weight + bias gradient partials and dy2 with bn_2's backward sums
+        PwBwd p;
+        p.g = g3; p.prev = a2; p.prev_mean = f.bn2.mean; p.prev_invstd = f.bn2.invstd;
+        p.W = P[HP_CONV3_W]; p.ldw = 128; p.out = b.dy2; p.dWpart = b.wpart; p.dbpart = b.dbpart;
+        p.part_a = b.part_a; p.part_b = b.part_b;
+        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
+        p.blocks_per_slot = pw_bwd_blocks(Q, 1, max_rows);
+        const int nblk = p.blocks_per_slot;
+        TRY(pw_bwd_fused(p, st));
+        TRY(reduce_windows(b.wpart, nblk, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
+        TRY(reduce_windows(b.dbpart, nblk, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = 1; fz.part_Q = nblk; fz.n_slots = 1; fz.C = 128;
+        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+        fz.gamma = P[HP_BN2_W]; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
+        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
+        TRY(bn_bwd_finalize(fz, st));
+    } else {
         PwWgrad w;
         w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
         w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
@@ -347,7 +362,23 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     // ---- conv_2: z2 = lo W2[:, :64]^T + (token W2[:, 64:]^T + b2)[window] ------------------------------------
     GradSrc g2;
     g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0];
-    {
+    // fused form: every workgroup stays inside one window, so its column sums of g2 are a per-window partial of the
+    // token-bias gradient
+    const int cpw = cdiv(max_rows, pw_bwd_item_rows());
+    int ipb = cpw < 4 ? cpw : 4;
+    while (cpw % ipb) --ipb;
+    const int bpw = cpw / ipb;                                  // workgroups per window
+    if (fused && bpw <= wch) {
+        PwBwd p;
+        p.g = g2; p.prev.z = lo; p.prev.C = 64;
+        p.W = P[HP_CONV2_W]; p.ldw = 320; p.out = d_lo; p.dWpart = b.wpart; p.dbpart = b.dbpart;
+        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
+        p.items_per_block = ipb; p.blocks_per_slot = Q * bpw;
+        TRY(pw_bwd_fused(p, st));
+        TRY(reduce_windows(b.wpart, Q * bpw, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
+        TRY(reduce_windows(b.dbpart, bpw, 128, Q, 128, bpw * 128, b.dgb, 128, 0, st));
+        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
+    } else {
         ActSrc yl;
         yl.z = lo; yl.C = 64;
         PwWgrad w;

@@ -223,10 +223,13 @@ struct PwBwd {
     const int *win_off = nullptr;
     int Q = 0, n_slots = 1, max_rows = 0;
     int blocks_per_slot = 0;       // filled by pw_bwd_blocks()
+    int items_per_block = 0;       // > 0: fixed share of (window, pw_bwd_item_rows()-row chunk) items per workgroup; a divisor of the
+                                   // chunks per window keeps every workgroup inside one window (per-window dbpart sums)
     long rows_hint = 0;
 };
 int pw_bwd_blocks(int Q, int n_slots, int max_rows);     // blocks_per_slot for this shape (grid = that * n_slots)
 bool pw_bwd_supported(int cx, int cy);
+int pw_bwd_item_rows();
 int pw_bwd_fused(const PwBwd &a, hipStream_t st);
 
 // dst[i] (= or +=) sum_q part[q * stride + i], i < n, fixed order; dst row-remap for strided destinations:

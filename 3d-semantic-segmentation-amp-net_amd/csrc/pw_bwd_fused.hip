@@ -25,7 +25,7 @@ constexpr int FB_ITEM_ROWS = 256;      // granularity of the work split inside a
 // GRAM: X operand = relu(z * P2 + P3) of the SAME tensor as z_{l-1} (pooled layers); otherwise dense dy with BatchNorm
 // constants.  YACT: the layer's input is relu(bn(z_{l-1})) (mask + sums), else z_{l-1} itself.  ADD: extra addend.
 // The modes are compile-time so that the prefetch loads sit in one basic block (no conservative vmcnt(0) between them).
-template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD>
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP = false>
 __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 {
     constexpr int LDG = CX + 4, LDZ = CY + 4;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
     const int cpw = (a.max_rows + FB_ITEM_ROWS - 1) / FB_ITEM_ROWS;
     const int n_items = per_slot * cpw;
-    const int ipb = (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
+    const int ipb = a.items_per_block > 0 ? a.items_per_block : (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
     const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
 
     // ---- stage the transposed weight and load the per-thread constants ----
@@ -173,6 +173,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const float c_i = (y_act && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
     const bool do_part = a.part_a != nullptr;
     float s_a = 0.f, s_b = 0.f;
+    const uint32_t dthr = drop_threshold(a.prev.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.prev.drop_p) : 1.0f;
 
     Pos cur, nxt;
     bool live = open_item(item_begin, cur);
@@ -200,6 +202,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 for (int j = 0; j < TYW; ++j) {
                     const float zv = z[kr * LDZ + 32 * (ty0 + j) + r];
                     yb[j] = y_act ? fmaxf(fmaf(zv, wys[j], wyt[j]), 0.f) : zv;
+                    if (DROP) {
+                        const uint32_t el = (uint32_t)(cur.row0 + kr) * (uint32_t)CY + (uint32_t)(32 * (ty0 + j) + r);
+                        yb[j] = (mix32(el ^ a.prev.drop_seed) >= dthr) ? yb[j] * dscale : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < TXW; ++i)
@@ -250,6 +256,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 float v = acc0[e] + acc1[e] + c_b;
                 if (ADD) v += addv[e];
                 if (YACT) {
+                    if (DROP) {
+                        const uint32_t el = (uint32_t)(trow0 + rr) * (uint32_t)CY + (uint32_t)dcol;
+                        v = (mix32(el ^ a.prev.drop_seed) >= dthr) ? v * dscale : 0.f;
+                    }
                     v = fmaf(zv[e], c_s, c_t) > 0.f ? v : 0.f;
                     const float vs = ok ? v : 0.f;
                     s_a += vs;
@@ -324,14 +334,16 @@ int pw_bwd_blocks(int Q, int n_slots, int max_rows)
     return bps < items ? bps : (items > 0 ? items : 1);
 }
 
-bool pw_bwd_supported(int cx, int cy) { return (cx == 128 && (cy == 128 || cy == 64)) || (cx == 64 && cy == 64); }
+int pw_bwd_item_rows() { return FB_ITEM_ROWS; }
 
-template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD>
+bool pw_bwd_supported(int cx, int cy) { return (cx == 128 && (cy == 128 || cy == 64)) || (cx == 64 && (cy == 64 || cy == 128)); }
+
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP = false>
 static int launch_fused_x(const PwBwd &a, hipStream_t st)
 {
     constexpr size_t lds = (size_t)(2 * ROWS * (CX + 4) + 2 * ROWS * (CY + 4) + CY * (CX + 4)) * sizeof(float);
     static bool attr_set = false;
-    auto kern = pw_bwd_kernel<CX, CY, ROWS, GRAM, YACT, ADD>;
+    auto kern = pw_bwd_kernel<CX, CY, ROWS, GRAM, YACT, ADD, DROP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_fused: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -350,6 +362,12 @@ template <int CX, int CY, int ROWS>
 static int launch_fused(const PwBwd &a, hipStream_t st)
 {
     const bool gram = a.g.act != 0, yact = a.prev.s != nullptr, add = a.add != nullptr;
+    if constexpr (CX == 64 && CY == 128) {
+        // the head's conv_3: its input is dropout(relu(bn_2(z2)))
+        if (gram || add || !yact) return fail(AMPNET_E_ARG, "pw_bwd_fused: 64 x 128 is built for an activated input without addend");
+        return a.prev.drop_p > 0.f ? launch_fused_x<CX, CY, ROWS, false, true, false, true>(a, st) : launch_fused_x<CX, CY, ROWS, false, true, false, false>(a, st);
+    }
+    if (a.prev.drop_p > 0.f) return fail(AMPNET_E_ARG, "pw_bwd_fused: dropout only built for 64 x 128");
     if (gram) {
         if (CX != CY || !yact || add) return fail(AMPNET_E_ARG, "pw_bwd_fused: Gram form needs CX == CY, an activated input and no addend");
         if constexpr (CX == CY) return launch_fused_x<CX, CY, ROWS, true, true, false>(a, st);
@@ -368,13 +386,13 @@ int pw_bwd_fused(const PwBwd &a, hipStream_t st)
     AMPNET_REQUIRE(a.W && a.out && a.dWpart && a.win_off && a.prev.z, "pw_bwd_fused: null pointer");
     AMPNET_REQUIRE(a.g.act ? a.g.z == a.prev.z : (a.g.dy && a.g.P1), "pw_bwd_fused: dense gradient with BatchNorm constants, or the Gram form of one tensor");
     AMPNET_REQUIRE(a.g.P2 && a.g.P3 && a.g.z, "pw_bwd_fused: BatchNorm constants incomplete");
-    AMPNET_REQUIRE(a.prev.drop_p == 0.f, "pw_bwd_fused: dropout layers go through pw_wgrad / pw_dgrad");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.s), "pw_bwd_fused: partial sums need the previous layer's BatchNorm");
     AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
     AMPNET_REQUIRE(a.prev.C == 0 || pw_bwd_supported(a.g.C, a.prev.C), "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
     if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);
     if (a.g.C == 128 && a.prev.C == 64) return launch_fused<128, 64, 64>(a, st);
     if (a.g.C == 64 && a.prev.C == 64) return launch_fused<64, 64, 64>(a, st);
+    if (a.g.C == 64 && a.prev.C == 128) return launch_fused<64, 128, 32>(a, st);
     return fail(AMPNET_E_ARG, "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
 }
 
