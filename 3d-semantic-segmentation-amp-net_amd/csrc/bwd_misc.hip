@@ -4,6 +4,8 @@
 
 namespace ampnet {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ----------------------------------------------------------------------------------------------------
 // bn_bwd_finalize: block = (slot, 64 channels) x 4 groups over the slot's partials, fixed order
 // ----------------------------------------------------------------------------------------------------
@@ -20,11 +22,21 @@ __global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinal
     double sa = 0.0, sb = 0.0;
     if (c < a.C) {
         const int total = part_per_slot * a.chunks;
-        for (int e = g; e < total; e += BFIN_G) {
-            const int q = slot + (e / a.chunks) * a.n_slots;
-            const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
-            sa += (double)a.part_a[o];
-            sb += (double)a.part_b[o];
+        for (int e0 = g; e0 < total; e0 += BFIN_G * 8) {          // eight independent loads per array in flight
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + BFIN_G * u;
+                const int q = slot + (e / a.chunks) * a.n_slots;
+                const size_t o = (size_t)(q * a.chunks + e % a.chunks) * a.C + c;
+                va[u] = e < total ? a.part_a[o] : 0.f;
+                vb[u] = e < total ? a.part_b[o] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sa += (double)va[u];
+                sb += (double)vb[u];
+            }
         }
     }
     ra[g][cl] = sa;
@@ -104,30 +116,59 @@ int bn_param_grads(const BnGradItem *items, int n, hipStream_t st)
 // rows and the forward kept their pre-BatchNorm values (zext), so the whole BatchNorm-backward reduction of the
 // pooled layer is B table look-ups per channel: the [rows, 256] output is never needed again.
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
+constexpr int PB_G = 16;       // window groups per channel (block = 64 channels x 16 groups)
+
+__global__ __launch_bounds__(64 * PB_G) void pool_bwd_kernel(PoolBwd a)
 {
-    const int slot = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
-    if (c >= a.C) return;
-    const size_t so = (size_t)slot * a.C + c;
+    __shared__ double rA[PB_G][64], rB[PB_G][64];
+    __shared__ int rR[PB_G];
+    const int slot = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.y * 64 + cl;
+    const bool ok = c < a.C;
+    const size_t so = (size_t)slot * a.C + (ok ? c : 0);
     const float sc = a.scale[so], sh = a.shift[so], mean = a.mean[so], invstd = a.invstd[so];
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
     double A = 0.0, Bs = 0.0;
     int rows = 0;
-    for (int i = 0; i < per_slot; ++i) {
-        const int q = slot + i * a.n_slots;
-        rows += a.win_off[q + 1] - a.win_off[q];
-        const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
-        const int row = a.arg[(size_t)q * a.C + c];
-        float d = 0.f;
-        if (row >= 0) {
-            const float zv = a.zext[(size_t)q * a.C + c];
-            if (fmaf(zv, sc, sh) > 0.f) {
-                d = a.d_pooled[(size_t)prow * a.C + c];
-                A += (double)d;
-                Bs += (double)d * (double)((zv - mean) * invstd);
-            }
+    // four windows per trip, every load issued before the first use
+    for (int i0 = g; i0 < per_slot; i0 += PB_G * 4) {
+        int rowv[4], prw[4];
+        float zv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + PB_G * u;
+            const bool live = i < per_slot && ok;
+            const int q = slot + (live ? i : 0) * a.n_slots;
+            prw[u] = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+            rowv[u] = live ? a.arg[(size_t)q * a.C + c] : -2;
+            zv[u] = live ? a.zext[(size_t)q * a.C + c] : 0.f;
+            dv[u] = live ? a.d_pooled[(size_t)prw[u] * a.C + c] : 0.f;
+            if (cl == 0 && i < per_slot) rows += a.win_off[q + 1] - a.win_off[q];
         }
-        a.dpm[(size_t)prow * a.C + c] = d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (rowv[u] == -2) continue;
+            float d = 0.f;
+            if (rowv[u] >= 0 && fmaf(zv[u], sc, sh) > 0.f) {
+                d = dv[u];
+                A += (double)d;
+                Bs += (double)d * (double)((zv[u] - mean) * invstd);
+            }
+            a.dpm[(size_t)prw[u] * a.C + c] = d;
+        }
+    }
+    rA[g][cl] = A;
+    rB[g][cl] = Bs;
+    if (cl == 0) rR[g] = rows;
+    __syncthreads();
+    if (g != 0 || !ok) return;
+    A = 0.0;
+    Bs = 0.0;
+    rows = 0;
+#pragma unroll
+    for (int k = 0; k < PB_G; ++k) {
+        A += rA[k][cl];
+        Bs += rB[k][cl];
+        rows += rR[k];
     }
     const double n = (double)rows;
     const double gamma_invstd = (double)sc;      // scale = gamma * invstd
@@ -142,7 +183,7 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(PoolBwd a)
 int pool_bwd(const PoolBwd &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.d_pooled && a.arg && a.zext && a.scale && a.shift && a.mean && a.invstd && a.win_off && a.dpm && a.P1 && a.P2 && a.P3 && a.slot_ab, "pool_bwd: null pointer");
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * PB_G), 0, st, a);
     return check_launch("pool_bwd_kernel");
 }
 
@@ -523,13 +564,23 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(SparseRows a)
     __shared__ unsigned char sIsDup[256];
     sIsDup[c] = dup ? 1 : 0;
     __syncthreads();
-    for (int cc = wv; cc < a.C; cc += 4) {                    // one wave per channel, lanes over k
-        const int rr = sArg[cc];
-        if (rr < 0) continue;
-        if (sIsDup[cc]) continue;
-        const float cf = sCoef[cc];
-        const int i = sIdx[cc];
-        for (int k = lane; k < a.cp; k += 64) out[(size_t)i * a.cp + k] = cf * a.W[(size_t)cc * a.cp + k];
+    {
+        // thread = (channel group, 16-byte column): cp / 4 columns, 256 / (cp / 4) channels per trip, eight trips in flight
+        const int qn = a.cp / 4, cstep = 256 / qn, kq = tid % qn, cg = tid / qn;
+        for (int c0 = cg; c0 < a.C; c0 += cstep * 8) {
+            f32x4 wv4[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cc = c0 + cstep * u;
+                const bool own = cc < a.C && sArg[cc] >= 0 && !sIsDup[cc];
+                wv4[u] = own ? *reinterpret_cast<const f32x4 *>(a.W + (size_t)cc * a.cp + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cc = c0 + cstep * u;
+                if (cc < a.C && sArg[cc] >= 0 && !sIsDup[cc]) *reinterpret_cast<f32x4 *>(out + (size_t)sIdx[cc] * a.cp + 4 * kq) = wv4[u] * sCoef[cc];
+            }
+        }
     }
     __syncthreads();
     // ... then the few merged channels are added in channel order (same thread per column: reproducible)
@@ -545,7 +596,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(SparseRows a)
 int sparse_rows(const SparseRows &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.srows && a.srow_row && a.srow_cnt, "sparse_rows: null pointer");
-    AMPNET_REQUIRE(a.cp <= 256 && a.C <= 256, "sparse_rows: C=%d cp=%d", a.C, a.cp);
+    AMPNET_REQUIRE(a.cp <= 256 && a.C <= 256 && a.cp % 4 == 0 && 256 % (a.cp / 4) == 0, "sparse_rows: C=%d cp=%d", a.C, a.cp);
     hipLaunchKernelGGL(sparse_rows_kernel, dim3(a.Q), dim3(256), 0, st, a);
     return check_launch("sparse_rows_kernel");
 }
@@ -560,15 +611,27 @@ __global__ __launch_bounds__(128) void sparse_fix_kernel(SparseFix a)
     const float mu = a.mean_prev[(size_t)slot * a.cp + k], is = a.invstd_prev[(size_t)slot * a.cp + k];
     const int n = a.srow_cnt[q];
     float sa = 0.f, sb = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-        const int row = a.srow_row[(size_t)q * a.C + i];
-        const float zv = a.z_prev[(size_t)row * a.cp + k];
-        const float sv = a.srows[((size_t)q * a.C + i) * a.cp + k];
-        const float v = fmaf(zv, sc, sh) > 0.f ? sv : 0.f;
-        a.out[(size_t)row * a.cp + k] += v;            // each row appears once per window: no conflict
-        sa += v;
-        sb = fmaf(v, (zv - mu) * is, sb);
+    // eight rows per trip: their loads (row index, z, the scattered row, the current output) are all in flight before
+    // the first store -- the rows of one window are distinct, so the read-modify-writes do not alias
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        int rowv[8];
+        float zv[8], sv[8], ov[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rowv[u] = a.srow_row[(size_t)q * a.C + min(i0 + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            zv[u] = a.z_prev[(size_t)rowv[u] * a.cp + k];
+            sv[u] = a.srows[((size_t)q * a.C + min(i0 + u, n - 1)) * a.cp + k];
+            ov[u] = a.out[(size_t)rowv[u] * a.cp + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= n) continue;
+            const float v = fmaf(zv[u], sc, sh) > 0.f ? sv[u] : 0.f;
+            a.out[(size_t)rowv[u] * a.cp + k] = ov[u] + v;
+            sa += v;
+            sb = fmaf(v, (zv[u] - mu) * is, sb);
+        }
     }
     const size_t o = (size_t)(q * a.part_chunks + a.slot_idx) * a.cp + k;
     a.part_a[o] = sa;
@@ -628,48 +691,61 @@ int reduce_slots(const float *part, int Q, int chunks, int n_slots, int n_el, fl
 }
 
 // block = output channel c, thread = input channel k
-__global__ __launch_bounds__(128) void pooled_wgrad_kernel(PooledWgrad a)
+constexpr int PWG_G = 4;       // thread groups per output channel: 4 x more gathers in flight than one group
+
+__global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a)
 {
     __shared__ float sW[256];
-    extern __shared__ int sDyn[];         // [Q] argmax row (clamped to 0), [Q] coefficient (as float bits)
+    __shared__ float sRed[PWG_G][128];
+    extern __shared__ int sDyn[];         // [Q] argmax row (clamped to 0), [Q] coefficient, [S][cp] scale, [S][cp] shift
     int *sRow = sDyn;
     float *sCoef = reinterpret_cast<float *>(sDyn + a.Q);
-    const int c = blockIdx.x, k = threadIdx.x;
-    for (int j = k; j < a.cp; j += 128) sW[j] = a.W[(size_t)c * a.cp + j];
-    for (int q = k; q < a.Q; q += 128) {
+    float *sS = sCoef + a.Q, *sT = sS + a.n_slots * a.cp;
+    const int c = blockIdx.x, tid = threadIdx.x, k = tid & 127, grp = tid >> 7;
+    for (int j = tid; j < a.cp; j += 128 * PWG_G) sW[j] = a.W[(size_t)c * a.cp + j];
+    for (int q = tid; q < a.Q; q += 128 * PWG_G) {
         const int r = a.arg[(size_t)q * a.C + c];
         const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
         const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
         sRow[q] = r < 0 ? 0 : r;
         sCoef[q] = r < 0 ? 0.f : a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c];
     }
+    for (int e = tid; e < a.n_slots * a.cp; e += 128 * PWG_G) {
+        sS[e] = a.s_prev[e];
+        sT[e] = a.t_prev[e];
+    }
     __syncthreads();
-    if (k >= a.cp) return;
     float acc = 0.f;
-    for (int s = 0; s < a.n_slots; ++s) {
-        float m = 0.f;
-        const float *g = a.gram + (size_t)s * a.cp * a.cp;
+    if (k < a.cp) {
+        // dense part: slots s = grp, grp + 4, ...
+        for (int s = grp; s < a.n_slots; s += PWG_G) {
+            float m = 0.f;
+            const float *g = a.gram + (size_t)s * a.cp * a.cp;
 #pragma unroll 8
-        for (int j = 0; j < a.cp; ++j) m = fmaf(sW[j], g[(size_t)j * a.cp + k], m);
-        acc = fmaf(a.P2[(size_t)s * a.C + c], m, acc);
-        acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
-    }
-    // sparse part: gathers of the argmax rows, independent loads (no branches) so that they pipeline
-    const float *__restrict__ zp = a.z_prev;
+            for (int j = 0; j < a.cp; ++j) m = fmaf(sW[j], g[(size_t)j * a.cp + k], m);
+            acc = fmaf(a.P2[(size_t)s * a.C + c], m, acc);
+            acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
+        }
+        // sparse part: gathers of the argmax rows, windows q = grp, grp + 4, ...; independent loads so that they pipeline
+        const float *__restrict__ zp = a.z_prev;
 #pragma unroll 8
-    for (int q = 0; q < a.Q; ++q) {
-        const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
-        const float av = fmaxf(fmaf(zp[(size_t)sRow[q] * a.cp + k], a.s_prev[(size_t)slot * a.cp + k], a.t_prev[(size_t)slot * a.cp + k]), 0.f);
-        acc = fmaf(sCoef[q], av, acc);
+        for (int q = grp; q < a.Q; q += PWG_G) {
+            const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+            const float av = fmaxf(fmaf(zp[(size_t)sRow[q] * a.cp + k], sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
+            acc = fmaf(sCoef[q], av, acc);
+        }
     }
-    a.dW[(size_t)c * a.cp + k] = acc;
+    sRed[grp][k] = acc;
+    __syncthreads();
+    if (grp == 0 && k < a.cp) a.dW[(size_t)c * a.cp + k] = (sRed[0][k] + sRed[1][k]) + (sRed[2][k] + sRed[3][k]);
 }
 
 int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.W && a.P1 && a.P2 && a.P3 && a.gram && a.asum && a.arg && a.dpm && a.z_prev && a.s_prev && a.t_prev && a.dW, "pooled_wgrad: null pointer");
-    AMPNET_REQUIRE(a.cp <= 128 && a.Q * 2 * sizeof(int) <= 48 * 1024, "pooled_wgrad: cp=%d Q=%d", a.cp, a.Q);
-    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3(a.C), dim3(128), a.Q * 2 * sizeof(int), st, a);
+    const size_t lds = ((size_t)a.Q * 2 + (size_t)a.n_slots * a.cp * 2) * sizeof(int);
+    AMPNET_REQUIRE(a.cp <= 128 && lds <= 60 * 1024, "pooled_wgrad: cp=%d Q=%d n_slots=%d", a.cp, a.Q, a.n_slots);
+    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
     return check_launch("pooled_wgrad_kernel");
 }
 

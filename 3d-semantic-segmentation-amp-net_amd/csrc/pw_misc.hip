@@ -121,14 +121,32 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;     // windows q = slot, slot + n_slots, ...
     const int total = per_slot * a.chunks;
     const bool ok = c < a.C;
-    double n = 0.0, sm = 0.0;
-    for (int e = g; e < total; e += FIN_G) {
+    // the partial loads are issued eight at a time before anything consumes them: a load -> use -> load chain costs one
+    // memory round trip per partial (16 per thread at B = 64), which was the whole run time of this kernel
+    auto rows_of = [&](int e) -> int {
         const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
         const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
-        const int rows = min(wrows - ch * a.chunk_rows, a.chunk_rows);
-        if (rows <= 0 || !ok) continue;
-        n += (double)rows;
-        sm += (double)rows * (double)a.part_sum[(size_t)(q * a.chunks + ch) * a.C + c];
+        return max(min(wrows - ch * a.chunk_rows, a.chunk_rows), 0);
+    };
+    auto off_of = [&](int e) -> size_t {
+        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
+        return (size_t)(q * a.chunks + ch) * a.C + c;
+    };
+    double n = 0.0, sm = 0.0;
+    for (int e0 = g; e0 < total; e0 += FIN_G * 8) {
+        float v[8];
+        int rw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + FIN_G * u;
+            rw[u] = (e < total && ok) ? rows_of(e) : 0;
+            v[u] = rw[u] > 0 ? a.part_sum[off_of(e)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            n += (double)rw[u];
+            sm += (double)rw[u] * (double)v[u];
+        }
     }
     rn[g][cl] = n;
     rs[g][cl] = sm;
@@ -142,14 +160,21 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
     const double mean = N > 0.0 ? S / N : 0.0;
     __syncthreads();
     double m2 = 0.0;
-    for (int e = g; e < total; e += FIN_G) {
-        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
-        const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
-        const int rows = min(wrows - ch * a.chunk_rows, a.chunk_rows);
-        if (rows <= 0 || !ok) continue;
-        const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
-        const double d = (double)a.part_sum[o] - mean;
-        m2 += (double)a.part_sq[o] + (double)rows * d * d;
+    for (int e0 = g; e0 < total; e0 += FIN_G * 8) {
+        float v[8], w[8];
+        int rw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + FIN_G * u;
+            rw[u] = (e < total && ok) ? rows_of(e) : 0;
+            v[u] = rw[u] > 0 ? a.part_sum[off_of(e)] : 0.f;
+            w[u] = rw[u] > 0 ? a.part_sq[off_of(e)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double d = (double)v[u] - mean;
+            m2 += rw[u] > 0 ? (double)w[u] + (double)rw[u] * d * d : 0.0;
+        }
     }
     rs[g][cl] = m2;
     __syncthreads();
