@@ -28,6 +28,7 @@ struct HeadWs {
     float *z2, *z3;                                // [R,128] [R,64]
     int *tok_off;                                  // [2] = {0, Q}
     float *part_sum, *part_sq;                     // [max(Q*chunks, tok_chunks), 128]
+    float *merge;                                  // two-stage bn_finalize scratch
     float *loss_part;                              // [blocks, 2]
     BnSlot1 bn2, bn3;
     size_t bytes;

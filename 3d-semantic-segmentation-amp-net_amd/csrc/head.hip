@@ -71,6 +71,7 @@ void head_carve(const HeadShape &s, void *base, HeadWs &ws)
     const size_t np = (Q * (size_t)s.chunks > (size_t)s.tok_chunks ? Q * (size_t)s.chunks : (size_t)s.tok_chunks) * 128;
     ws.part_sum = c.take<float>(np);
     ws.part_sq = c.take<float>(np);
+    ws.merge = c.take<float>(bn_finalize_merge_floats(1, 128));
     ws.loss_part = c.take<float>((size_t)cdiv(s.R, 128) * 2);
     carve_bn(c, ws.bn2, 128);
     carve_bn(c, ws.bn3, 64);
@@ -145,6 +146,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         f.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
         f.gamma = P[wi]; f.beta = P[bi];
         f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
+        f.merge_ws = ws.merge;
         return bn_finalize(f, st);
     };
     {   // conv_2: local half + per-window token bias

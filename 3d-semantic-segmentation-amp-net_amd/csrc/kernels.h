@@ -75,7 +75,10 @@ struct BnFinalize {
     float *scale = nullptr, *shift = nullptr;   // [n_slots, C]   y = z * scale + shift
     float *mean = nullptr, *invstd = nullptr;   // [n_slots, C]   (saved for backward)
     float *stat_mean = nullptr, *stat_uvar = nullptr;   // [n_slots, C] batch mean / unbiased var for the running update
+    const int *part_rows = nullptr; // explicit rows per partial [Q * chunks] (instead of win_off / chunk_rows)
+    float *merge_ws = nullptr;     // optional scratch, bn_finalize_merge_floats(n_slots, C) floats: enables the two-stage form
 };
+inline size_t bn_finalize_merge_floats(int n_slots, int C) { return (size_t)n_slots * 16 * (2 * (size_t)C + 1); }
 int bn_finalize(const BnFinalize &a, hipStream_t st);
 
 // eval mode: scale/shift from running statistics for a list of layers, one launch

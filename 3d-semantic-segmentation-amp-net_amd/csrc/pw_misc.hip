@@ -109,8 +109,11 @@ int pw_input(const PwInput &a, hipStream_t st)
 // windows in double, in a fixed order: bitwise reproducible run to run.
 // ----------------------------------------------------------------------------------------------------
 constexpr int FIN_G = 16;      // partial groups per channel (block = 64 channels x 16 groups)
+constexpr int FIN_V = 16;      // two-stage form: sub-slots per slot merged first (few slots x thousands of partials)
 
-__global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
+// MERGE: write the merged (mean, M2, rows) of the block's (sub-)slot as a partial instead of the BatchNorm constants.
+template <bool MERGE>
+__global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a, float *out_sum, float *out_sq, int *out_rows)
 {
     // two passes over the slot's chunk partials (n_i, mean_i, M2_i), no division inside the loops:
     //   mean = sum n_i mean_i / N;   M2 = sum (M2_i + n_i (mean_i - mean)^2)
@@ -121,17 +124,23 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;     // windows q = slot, slot + n_slots, ...
     const int total = per_slot * a.chunks;
     const bool ok = c < a.C;
+    const int sh = (a.chunks & (a.chunks - 1)) == 0 ? __ffs(a.chunks) - 1 : -1;    // chunks = 2^sh: no division
+    // element e of the slot -> (rows of that chunk, offset of its partial); one division at most
+    auto decode = [&](int e, int &rows, size_t &off) {
+        const int qi = sh >= 0 ? e >> sh : e / a.chunks;
+        const int ch = e - qi * a.chunks;
+        const int q = slot + qi * a.n_slots;
+        const int p = q * a.chunks + ch;
+        if (a.part_rows) {
+            rows = a.part_rows[p];
+        } else {
+            const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
+            rows = max(min(wrows - ch * a.chunk_rows, a.chunk_rows), 0);
+        }
+        off = (size_t)p * a.C + c;
+    };
     // the partial loads are issued eight at a time before anything consumes them: a load -> use -> load chain costs one
-    // memory round trip per partial (16 per thread at B = 64), which was the whole run time of this kernel
-    auto rows_of = [&](int e) -> int {
-        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
-        const int wrows = a.uniform_rows > 0 ? a.uniform_rows : a.win_off[q + 1] - a.win_off[q];
-        return max(min(wrows - ch * a.chunk_rows, a.chunk_rows), 0);
-    };
-    auto off_of = [&](int e) -> size_t {
-        const int q = slot + (e / a.chunks) * a.n_slots, ch = e % a.chunks;
-        return (size_t)(q * a.chunks + ch) * a.C + c;
-    };
+    // memory round trip per partial
     double n = 0.0, sm = 0.0;
     for (int e0 = g; e0 < total; e0 += FIN_G * 8) {
         float v[8];
@@ -139,8 +148,10 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + FIN_G * u;
-            rw[u] = (e < total && ok) ? rows_of(e) : 0;
-            v[u] = rw[u] > 0 ? a.part_sum[off_of(e)] : 0.f;
+            size_t off = 0;
+            rw[u] = 0;
+            if (e < total && ok) decode(e, rw[u], off);
+            v[u] = rw[u] > 0 ? a.part_sum[off] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -166,9 +177,11 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + FIN_G * u;
-            rw[u] = (e < total && ok) ? rows_of(e) : 0;
-            v[u] = rw[u] > 0 ? a.part_sum[off_of(e)] : 0.f;
-            w[u] = rw[u] > 0 ? a.part_sq[off_of(e)] : 0.f;
+            size_t off = 0;
+            rw[u] = 0;
+            if (e < total && ok) decode(e, rw[u], off);
+            v[u] = rw[u] > 0 ? a.part_sum[off] : 0.f;
+            w[u] = rw[u] > 0 ? a.part_sq[off] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -182,10 +195,16 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
         m2 = 0.0;
 #pragma unroll
         for (int k = 0; k < FIN_G; ++k) m2 += rs[k][cl];
+        const size_t o = (size_t)slot * a.C + c;
+        if (MERGE) {
+            out_sum[o] = (float)mean;
+            out_sq[o] = (float)m2;
+            if (c == 0) out_rows[slot] = (int)N;
+            return;
+        }
         const double var = N > 0.0 ? m2 / N : 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
         const float sc = a.gamma[c] * invstd;
-        const size_t o = (size_t)slot * a.C + c;
         a.scale[o] = sc;
         a.shift[o] = a.beta[c] - (float)mean * sc;
         if (a.mean) a.mean[o] = (float)mean;
@@ -199,8 +218,24 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a)
 
 int bn_finalize(const BnFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_sum && a.part_sq && a.win_off && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, a);
+    AMPNET_REQUIRE(a.part_sum && a.part_sq && (a.win_off || a.part_rows) && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
+    const long per_slot_parts = (long)((a.Q + a.n_slots - 1) / a.n_slots) * a.chunks;
+    if (a.merge_ws && per_slot_parts > 1024 && a.n_slots * FIN_V <= a.Q) {
+        // few slots, thousands of partials each (the head: one slot): merge FIN_V sub-slots per slot on FIN_V x more
+        // workgroups first, then finalize those
+        const int V = a.n_slots * FIN_V;
+        float *m_sum = a.merge_ws, *m_sq = m_sum + (size_t)V * a.C;
+        int *m_rows = reinterpret_cast<int *>(m_sq + (size_t)V * a.C);
+        BnFinalize s1 = a;
+        s1.n_slots = V;
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(V, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, s1, m_sum, m_sq, m_rows);
+        BnFinalize s2 = a;
+        s2.part_sum = m_sum; s2.part_sq = m_sq; s2.part_rows = m_rows;
+        s2.Q = V; s2.chunks = 1; s2.uniform_rows = 0;
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, s2, nullptr, nullptr, nullptr);
+        return check_launch("bn_finalize_kernel (two stages)");
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, a, nullptr, nullptr, nullptr);
     return check_launch("bn_finalize_kernel");
 }
 
