@@ -57,6 +57,21 @@ def lib():
     return l
 
 
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+def set_matrix_precision(mode):
+    """'fp32' (default, exact fp32 products: the mode the parity figures hold in) or 'bf16' (the forward per-point layers
+    round their MFMA operands to bf16, fp32 accumulation; include/ampnet_hip.h: ampnet_set_matrix_precision)."""
+    if mode not in PRECISIONS:
+        raise AmpnetError(f"unknown matrix precision {mode!r}: one of {sorted(PRECISIONS)}")
+    check(lib().ampnet_set_matrix_precision(PRECISIONS[mode]), "ampnet_set_matrix_precision")
+
+
+def get_matrix_precision():
+    return "bf16" if lib().ampnet_get_matrix_precision() == 1 else "fp32"
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().ampnet_last_error()

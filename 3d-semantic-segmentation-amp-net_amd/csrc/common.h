@@ -35,6 +35,9 @@ struct ProfScope {
     hipStream_t st;
 };
 
+// process-wide MFMA operand precision (ampnet_set_matrix_precision)
+int matrix_precision();
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

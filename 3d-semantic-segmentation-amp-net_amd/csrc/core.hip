@@ -92,6 +92,19 @@ extern "C" int ampnet_profile_read(int max_rows, char *names, double *ms, long l
     return n;
 }
 
+namespace ampnet {
+static int g_matrix_precision = AMPNET_PRECISION_F32;
+int matrix_precision() { return g_matrix_precision; }
+}  // namespace ampnet
+
+extern "C" int ampnet_set_matrix_precision(int mode)
+{
+    if (mode != AMPNET_PRECISION_F32 && mode != AMPNET_PRECISION_BF16) return ampnet::fail(AMPNET_E_ARG, "ampnet_set_matrix_precision: mode %d", mode);
+    ampnet::g_matrix_precision = mode;
+    return AMPNET_OK;
+}
+extern "C" int ampnet_get_matrix_precision(void) { return ampnet::g_matrix_precision; }
+
 extern "C" int ampnet_abi_version(void) { return AMPNET_ABI_VERSION; }
 extern "C" const char *ampnet_last_error(void) { return ampnet::err_buf(); }
 

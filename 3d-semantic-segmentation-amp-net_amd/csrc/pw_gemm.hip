@@ -23,6 +23,19 @@ namespace ampnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi)
+{
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[i] = (__bf16)lo[i];          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+        o[4 + i] = (__bf16)hi[i];
+    }
+    return o;
+}
 
 constexpr int PW_NW = 4;   // waves per workgroup
 
@@ -34,15 +47,20 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // PRO: prologue on the A operand -- 0 none, 1 relu(a * scale + shift), 2 the same then dropout.  POOL: track the per-channel
 // extreme (+ its row) instead of / besides storing.  Both are compile-time so that the K loop and the epilogue are straight-line
 // code: LDS reads get scheduled ahead of the MFMAs that use them and no branch sits between two epilogue elements.
-template <int CIN, int NT, int PRO, bool POOL>
+// BF: the MFMA operands are rounded to bf16 (activations after the prologue, weights while staged) and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 16 x the fp32 matrix rate; HBM tensors, BatchNorm statistics, the
+// prologue and the epilogue stay fp32 (ampnet_set_matrix_precision).  Lane (r, h) then owns k = 16 s + 8 h .. + 7 of step s.
+template <int CIN, int NT, int PRO, bool POOL, bool BF>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
     constexpr int CB = 32 * NT;
-    constexpr int LDW = CIN + 4;
+    constexpr int LDW = CIN + 4;       // fp32 weight row (floats)
+    constexpr int LDB = CIN + 8;       // bf16 weight row (elements): 16-byte aligned rows, conflict-free ds_read_b128
     constexpr int NBLK = CIN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sW = smem;                  // [CB][LDW]
-    float *sPro = smem + CB * LDW;     // scale[CIN], shift[CIN]
+    float *sW = smem;                  // fp32: [CB][LDW]
+    __bf16 *sWb = reinterpret_cast<__bf16 *>(smem);   // bf16: [CB][LDB]
+    float *sPro = BF ? smem + CB * LDB / 2 : smem + CB * LDW;     // scale[CIN], shift[CIN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,13 +87,22 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 const int j = e / (CIN / 4), k4 = e % (CIN / 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cb0 + j < a.cout) v = *reinterpret_cast<const f32x4 *>(Wg + (size_t)(cb0 + j) * a.ldw + 4 * k4);
-                *reinterpret_cast<f32x4 *>(sW + j * LDW + 4 * k4) = v;
+                if (BF) {
+                    bf16x4 b;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[i];
+                    *reinterpret_cast<bf16x4 *>(sWb + j * LDB + 4 * k4) = b;
+                } else {
+                    *reinterpret_cast<f32x4 *>(sW + j * LDW + 4 * k4) = v;
+                }
             }
         } else {
             const float *Wg = a.W + (size_t)pidx * a.w_win_stride;   // [CIN][cout]
             for (int e = tid; e < CIN * CB; e += PW_NW * 64) {
                 const int k = e / CB, j = e % CB;
-                sW[j * LDW + k] = (cb0 + j < a.cout) ? Wg[(size_t)k * a.cout + cb0 + j] : 0.f;
+                const float v = (cb0 + j < a.cout) ? Wg[(size_t)k * a.cout + cb0 + j] : 0.f;
+                if (BF) sWb[j * LDB + k] = (__bf16)v;
+                else sW[j * LDW + k] = v;
             }
         }
         if (PRO) {
@@ -123,14 +150,16 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         const int row0 = row_begin + tile * 32;
         const int valid = min(32, row_end - row0);
         const int arow = row0 + min(r, valid - 1);
-        return a.A + (size_t)arow * a.lda + 32 * kb + 4 * h;
+        return a.A + (size_t)arow * a.lda + 32 * kb + (BF ? 8 : 4) * h;
     };
+    // float offset of the j-th 16-byte piece of a 32-k block: fp32 k = 8 j + 4 h .. + 3; bf16 k = 16 (j / 2) + 8 h + 4 (j & 1) .. + 3
+    auto frag_off = [](int j) -> int { return BF ? 16 * (j >> 1) + 4 * (j & 1) : 8 * j; };
 
     int tile = wave;
     if (tile < ntiles) {
         const float *ap = frag_ptr(tile, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = *reinterpret_cast<const f32x4 *>(ap + 8 * j);
+        for (int j = 0; j < 4; ++j) a_cur[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
     }
     for (; tile < ntiles; tile += PW_NW) {
         const int row0 = row_begin + tile * 32;
@@ -154,11 +183,41 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 if (ptile < ntiles) {
                     const float *ap = frag_ptr(ptile, pkb);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) a_nxt[j] = *reinterpret_cast<const f32x4 *>(ap + 8 * j);
+                    for (int j = 0; j < 4; ++j) a_nxt[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
+                }
+            }
+            if (BF) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int k0 = 32 * kb + 16 * s2 + 8 * h;
+                    f32x4 lo = a_cur[2 * s2], hi = a_cur[2 * s2 + 1];
+                    if (PRO) {
+                        const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sPro + k0), sc1 = *reinterpret_cast<const f32x4 *>(sPro + k0 + 4);
+                        const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0), sh1 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0 + 4);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lo[i] = fmaxf(fmaf(lo[i], sc0[i], sh0[i]), 0.f);
+                            hi[i] = fmaxf(fmaf(hi[i], sc1[i], sh1[i]), 0.f);
+                        }
+                        if (PRO == 2) {
+                            const uint32_t e0 = (uint32_t)arow * (uint32_t)CIN + (uint32_t)k0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                lo[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? lo[i] * dscale : 0.f;
+                                hi[i] = (mix32((e0 + 4 + i) ^ dbase) >= dthr) ? hi[i] * dscale : 0.f;
+                            }
+                        }
+                    }
+                    const bf16x8 av = pack_bf16(lo, hi);
+                    bf16x8 bw[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bw[t] = *reinterpret_cast<const bf16x8 *>(sWb + (32 * t + r) * LDB + k0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[t], acc[t], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < (BF ? 0 : 4); ++j) {
                 const int k0 = 32 * kb + 8 * j + 4 * h;
                 f32x4 av = a_cur[j];
                 if (PRO) {
@@ -285,15 +344,15 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     }
 }
 
-template <int CIN, int NT, int PRO, bool POOL>
-static int launch_pw_x(const PwGemm &a, hipStream_t st)
+template <int CIN, int NT, int PRO, bool POOL, bool BF>
+static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
-    constexpr size_t lds_main = (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
+    constexpr size_t lds_main = BF ? (size_t)CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
     constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
     constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
     static bool attr_set = false;
-    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF>;
     if (!attr_set) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -303,11 +362,17 @@ static int launch_pw_x(const PwGemm &a, hipStream_t st)
     }
     dim3 grid(a.chunks, a.Q, cdiv(a.cout, CB));
     char name[64];
-    snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "");
+    snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
     const double rows = (double)a.rows_hint;
     ProfScope prof(name, 2.0 * rows * CIN * a.cout, rows * 4.0 * ((double)CIN * cdiv(a.cout, CB) + (a.Z ? a.cout : 0)), st);
     hipLaunchKernelGGL(kern, grid, dim3(PW_NW * 64), lds, st, a);
     return check_launch("pw_gemm_kernel");
+}
+
+template <int CIN, int NT, int PRO, bool POOL>
+static int launch_pw_x(const PwGemm &a, hipStream_t st)
+{
+    return matrix_precision() == AMPNET_PRECISION_BF16 ? launch_pw_y<CIN, NT, PRO, POOL, true>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
 }
 
 // the (prologue, pool) variants each shape is actually used with; anything else is an argument error

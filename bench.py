@@ -30,6 +30,7 @@ PKG = "3d-semantic-segmentation-amp-net_amd"
 
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec
+PEAK_MFMA_BF16_TFLOPS = 2500.0    # dense bf16 matrix peak (no sparsity)
 RIDGE = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9)
 N_POINTS, N_WIN = 2048, 9
 
@@ -99,10 +100,12 @@ def roofline_from(rows):
     top = max(rows, key=lambda r: r["ms"])
     per_ms = top["ms"] / top["calls"]
     intensity = top["flops"] / max(top["bytes"], 1.0)
-    if intensity >= RIDGE:
+    is_bf16 = top["name"].endswith(" bf16")
+    peak_tf = PEAK_MFMA_BF16_TFLOPS if is_bf16 else PEAK_MFMA_F32_TFLOPS
+    if intensity >= peak_tf * 1e3 / PEAK_HBM_GBPS:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
-        return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4), traffic=pmc_traffic_for(top["name"]),
+        return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s",
+                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"]),
                     algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
                     launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
@@ -231,6 +234,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
+                    help="MFMA operand precision of the forward per-point layers (fp32 accumulate, fp32 backward either way)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,6 +265,7 @@ def main():
 
     synth = sub("synthetic")
     S = sub("pointNet.amp_step")
+    sub("_lib").set_matrix_precision(args.precision)
     enc, att = build_models(dev, train=(mode == "train"))
     pc, tg, cent, _ = synth.sample_batch(100 + rank, B, N_POINTS, max_w=N_WIN)
     x = torch.from_numpy(np.ascontiguousarray(pc.transpose(0, 3, 1, 2))).to(dev)          # [B, W, N, 9] resident in HBM
@@ -323,6 +329,27 @@ def main():
         fwd_ms = (time.perf_counter() - t2) / args.steps * 1e3
         enc.train(); att.train()
 
+    # informational leg: the same train step with bf16 MFMA operands in the forward layers (never the headline value)
+    bf16_leg = None
+    if mode == "train" and args.precision == "fp32":
+        sub("_lib").set_matrix_precision("bf16")
+        for _ in range(2):
+            step()
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt_bf = time.perf_counter() - t3
+        if dist is not None:
+            tt = torch.tensor([dt_bf], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_bf = float(tt.item())
+        sub("_lib").set_matrix_precision("fp32")
+        bf16_leg = {"ms_per_step": round(dt_bf / args.steps * 1e3, 4),
+                    "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1),
+                    "note": "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32"}
+
     if rank == 0:
         pts_step = B * N_WIN * N_POINTS
         value = world * pts_step * args.steps / dt
@@ -331,7 +358,7 @@ def main():
             "metric": "train points/sec + forward ms/window (N=2048)" if mode == "train" else "forward points/sec + forward ms/window (N=2048)",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 forward MFMA operands, f32 accumulate / statistics / backward", "data": "synthetic",
             "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"dp{world}"},
@@ -339,6 +366,7 @@ def main():
             "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
+            "bf16_forward_mode": bf16_leg,
             "roofline": roofline_from(rows),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))

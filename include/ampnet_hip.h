@@ -159,6 +159,16 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- matrix-core operand precision (process-wide) -----------------------------------------------------------
+ * AMPNET_PRECISION_F32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products -- the mode every parity figure is quoted in.
+ * AMPNET_PRECISION_BF16: the per-point layers of ampnet_encoder_fwd_f32 / ampnet_head_fwd_f32 round their MFMA operands
+ * (activations after BatchNorm+ReLU, weights) to bf16 and accumulate in fp32 (v_mfma_f32_32x32x16_bf16); tensors in HBM,
+ * BatchNorm statistics, loss and the whole backward stay fp32.  BASELINE.json config 3 ("bf16 MFMA MLP/attention").   */
+#define AMPNET_PRECISION_F32 0
+#define AMPNET_PRECISION_BF16 1
+int ampnet_set_matrix_precision(int mode);
+int ampnet_get_matrix_precision(void);
+
 /* ---- a12: baseline single-window PointNet segmentation, eval forward -----------------------------------------
  * replaces SegmentationPointNet.forward (module.eval()) of pointNet/model/pointnet.py:128-154 (variant 0: 1024-d,
  * convolutions with bias, T-Net on x[:, :, :3], :71) and of pointNet/model/light_pointnet_256.py:128-153 (variant 1:
