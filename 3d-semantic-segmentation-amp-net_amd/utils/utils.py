@@ -37,6 +37,32 @@ def fps_indices(xyz, n_samples):
     return idx[0] if single else idx
 
 
+def knn_indices(xyz, centres, k):
+    """Exact k-NN grouping on the GPU (BUILD-DEFINED: the reference has no k-NN, include/ampnet_hip.h: ampnet_knn_f32).
+    xyz [B, N, D>=3] float32 GPU, centres [B, S] int32 point indices (e.g. fps_indices) -> int32 [B, S, k]: per centre the k
+    points with the smallest (float32 squared distance, index), ascending; the centre itself comes first."""
+    _lib.require_gpu(xyz, "xyz")
+    _lib.require_gpu(centres, "centres")
+    if xyz.dim() != 3 or xyz.shape[2] < 3 or centres.dim() != 2 or centres.shape[0] != xyz.shape[0]:
+        raise _lib.AmpnetError(f"knn: expected xyz [B, N, D>=3] and centres [B, S], got {tuple(xyz.shape)} {tuple(centres.shape)}")
+    if centres.dtype != torch.int32:
+        raise _lib.AmpnetError("knn: centres must be int32")
+    x = xyz.float().contiguous()
+    c = centres.contiguous()
+    B, N, D = x.shape
+    S = c.shape[1]
+    k = int(k)
+    if not (1 <= k <= N):
+        raise IndexError(f"knn: k={k} out of range for {N} points")
+    if S and (int(c.min()) < 0 or int(c.max()) >= N):
+        raise IndexError("knn: centre index out of range")
+    out = torch.empty((B, S, k), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ampnet_knn_f32(_lib.ptr(x), B, N, D, _lib.ptr(c), S, k, _lib.ptr(out), _lib.stream_ptr(x.device))
+    _lib.check(rc, "ampnet_knn_f32")
+    return out
+
+
 def gather_rows(pc, idx):
     """pc [B, N, D] f32 GPU, idx [B, S] int32 -> [B, S, D] (the `pc[sample_inds]` of utils.py:933)."""
     _lib.require_gpu(pc, "pc")

@@ -198,6 +198,18 @@ def bench_fps(args, dev, rank, world, dist):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the second half of configs[4]: k-NN grouping (k = 32) of the FPS centres, build-defined spec (include/ampnet_hip.h)
+    K = 32
+    for _ in range(2):
+        grp = U.knn_indices(xyz, idx, K)
+    torch.cuda.synchronize(dev)
+    ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev2.record()
+    for _ in range(args.steps):
+        grp = U.knn_indices(xyz, idx, K)
+    ev3.record()
+    torch.cuda.synchronize(dev)
+    knn_ms = ev2.elapsed_time(ev3) / args.steps
     if rank == 0:
         alg_bytes = float(B) * S * N * 16
         ach = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -208,6 +220,10 @@ def bench_fps(args, dev, rank, world, dist):
                "roofline": {"bound": "hbm", "kernel": "fps_kernel<1024,8>", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "launch_ms": round(kern_ms, 4),
                             "note": "algorithmic 16 B per (candidate, round); the cloud is register-resident, true HBM traffic is B*(N*12+S*4) bytes"}}
+        knn_bytes = float(B) * S * N * 12
+        out["knn"] = {"k": K, "ms": round(knn_ms, 4), "centres_per_s": round(B * S / (knn_ms * 1e-3), 1),
+                      "achieved_GBps": round(knn_bytes / (knn_ms * 1e-3) / 1e9, 1),
+                      "note": "build-defined exact k-NN (the reference has none); algorithmic 12 B per (candidate, centre), served from LDS"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import fps_oracle
             pc = synth.clouds(200, 1, N)[0]

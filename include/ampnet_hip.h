@@ -159,6 +159,16 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- k-NN grouping of FPS centres (BUILD-DEFINED; BASELINE.json north_star / config 5) ------------------------------
+ * The reference has no k-NN or ball query: nothing is replaced, parity against it is "unpinned"; the spec
+ * below is pinned by oracle/fps_oracle.py:knn_indices.
+ *   xyz      [n_clouds, n, ld] float32 (first 3 columns used), n * 12 bytes <= 144 KB (n <= 12288)
+ *   centres  [n_clouds, s] int32 point indices (e.g. the output of ampnet_fps_f32)
+ *   out      [n_clouds, s, k] int32: for each centre the k points with the smallest (distance, index), ascending;
+ *            distance = float32 ((dx*dx + dy*dy) + dz*dz), no fused multiply-add; the centre itself comes first   */
+int ampnet_knn_f32(const float *xyz, int n_clouds, int n, int ld, const int32_t *centres, int s, int k, int32_t *out,
+                   void *stream);
+
 /* ---- matrix-core operand precision (process-wide) -----------------------------------------------------------
  * AMPNET_PRECISION_F32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products -- the mode every parity figure is quoted in.
  * AMPNET_PRECISION_BF16: the per-point layers of ampnet_encoder_fwd_f32 / ampnet_head_fwd_f32 round their MFMA operands
