@@ -75,21 +75,11 @@ def pmc_traffic_for(name):
     """HBM bytes per launch (read + write) of the kernel bench.py calls `name`, from the rocprofv3 PMC passes summarised
     in profiles/pmc_traffic.json (profiles/pmc_traffic.py; FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact).  None when the
     file or an unambiguous match is missing."""
-    import re
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    m = re.match(r"pw_gemm<(\d+),(\d+)>(.*)", name)
-    if not (os.path.exists(path) and m):
+    if not os.path.exists(path):
         return None
-    sym = f"ampnet::pw_gemm_kernel<{m.group(1)}, {int(m.group(2)) // 32}>|grid="
-    table = json.load(open(path))
-    cands = sorted(((int(k.split("=")[1]), v) for k, v in table.items() if k.startswith(sym)), key=lambda kv: -kv[0])
-    if not cands:
-        return None
-    if "+pool" in m.group(3):                       # the pooled 128 -> 256 launches: two column blocks = the largest grid
-        v = cands[0][1]
-    elif len(cands) == 1:
-        v = cands[0][1]
-    else:
+    v = json.load(open(path)).get("events", {}).get(name)
+    if not v:
         return None
     return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
 

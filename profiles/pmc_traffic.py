@@ -37,8 +37,24 @@ def main(src, dst):
             key = f"{sym.split('(')[0].replace('void ', '')}|grid={g}"
             res[key] = {"launches": len(rd), "read_bytes": sum(rd) / len(rd) * 1024 * 2,
                         "write_bytes": (sum(ww) / len(ww) * 1024) if ww else None}
+    # bench.py's event names -> the matching (symbol, grid) entry; where several grids share an event name (point layers vs
+    # the tiny T-Net FC launches of the same instantiation) the largest grid is the point-layer launch the roofline is about
+    import re
+    events = {}
+    for key, v in res.items():
+        sym, grid = key.split("|grid=")
+        name = None
+        m = re.match(r"ampnet::pw_gemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", sym)
+        if m:
+            name = f"pw_gemm<{m.group(1)},{32 * int(m.group(2))}>" + ("+pool" if m.group(4) == "true" else "+store") + (" bf16" if m.group(5) == "true" else "")
+        m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
+        if m:
+            name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "")
+        if name and (name not in events or int(grid) > events[name]["grid"]):
+            events[name] = dict(v, grid=int(grid), symbol=sym)
+    res["events"] = events
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
-    print(f"wrote {dst}: {len(res)} (kernel, grid) entries")
+    print(f"wrote {dst}: {len(res) - 1} (kernel, grid) entries, {len(events)} bench event names")
 
 
 if __name__ == "__main__":
