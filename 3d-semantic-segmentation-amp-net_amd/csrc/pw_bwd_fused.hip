@@ -12,6 +12,7 @@
 // Workgroups are persistent: (slot, j) walks a contiguous share of the (window, chunk) items of its slot, so the
 // per-workgroup partials are few (grid of them, not windows x chunks), every one belongs to one BatchNorm slot, and
 // weights / constants are staged once.  Fixed assignment, no atomics: bitwise reproducible.
+#include <type_traits>
 #include "kernels.h"
 
 namespace ampnet {
@@ -192,25 +193,38 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         if (more && w_role) load_regs(nxt);
         const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
         if (w_role) {
-#pragma unroll 4
+            // software pipeline: the operands of step s2 + 1 are read from LDS before the MFMAs of step s2 issue, so the
+            // matrix pipe never waits on an LDS round trip.  Gram form: x and y are the same activated tile (sG).
+            float xa_n[TXW], yb_n[TYW];
+            auto fetch = [&](int s2) {
+                const int kr = 2 * s2 + h;
+#pragma unroll
+                for (int i = 0; i < TXW; ++i) xa_n[i] = g[kr * LDG + 32 * (tx0 + i) + r];
+#pragma unroll
+                for (int j = 0; j < TYW; ++j) yb_n[j] = GRAM ? g[kr * LDG + 32 * (ty0 + j) + r] : z[kr * LDZ + 32 * (ty0 + j) + r];
+            };
+            fetch(0);
+#pragma unroll 8
             for (int s2 = 0; s2 < ROWS / 2; ++s2) {
                 const int kr = 2 * s2 + h;
                 float xa[TXW], yb[TYW];
 #pragma unroll
-                for (int i = 0; i < TXW; ++i) xa[i] = g[kr * LDG + 32 * (tx0 + i) + r];
+                for (int i = 0; i < TXW; ++i) xa[i] = xa_n[i];
 #pragma unroll
                 for (int j = 0; j < TYW; ++j) {
-                    const float zv = z[kr * LDZ + 32 * (ty0 + j) + r];
-                    yb[j] = y_act ? fmaxf(fmaf(zv, wys[j], wyt[j]), 0.f) : zv;
+                    yb[j] = (y_act && !GRAM) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];
                     if (DROP) {
                         const uint32_t el = (uint32_t)(cur.row0 + kr) * (uint32_t)CY + (uint32_t)(32 * (ty0 + j) + r);
                         yb[j] = (mix32(el ^ a.prev.drop_seed) >= dthr) ? yb[j] * dscale : 0.f;
                     }
                 }
+                if (s2 + 1 < ROWS / 2) fetch(s2 + 1);
+                __builtin_amdgcn_sched_barrier(0);        // keep the reads above the MFMAs (the scheduler sinks them to their use)
 #pragma unroll
                 for (int i = 0; i < TXW; ++i)
 #pragma unroll
                     for (int j = 0; j < TYW; ++j) acc_w[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i], yb[j], acc_w[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // the optional addend: all sixteen loads in flight before the MFMAs
@@ -232,15 +246,24 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             }
             const float *ga = g + (32 * rt + r) * LDG + 4 * h;
             const float *wb = sWt + dcol * LDG + 4 * h;
+            f32x4 g0 = *reinterpret_cast<const f32x4 *>(ga), w0 = *reinterpret_cast<const f32x4 *>(wb);
+            f32x4 g1 = *reinterpret_cast<const f32x4 *>(ga + 8), w1 = *reinterpret_cast<const f32x4 *>(wb + 8);
 #pragma unroll 4
             for (int j = 0; j < CX / 8; j += 2) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4 *>(ga + 8 * j), w0 = *reinterpret_cast<const f32x4 *>(wb + 8 * j);
-                const f32x4 g1 = *reinterpret_cast<const f32x4 *>(ga + 8 * j + 8), w1 = *reinterpret_cast<const f32x4 *>(wb + 8 * j + 8);
+                const f32x4 cg0 = g0, cw0 = w0, cg1 = g1, cw1 = w1;
+                if (j + 2 < CX / 8) {                       // next pair of fragments in flight behind the eight MFMAs below
+                    g0 = *reinterpret_cast<const f32x4 *>(ga + 8 * j + 16);
+                    w0 = *reinterpret_cast<const f32x4 *>(wb + 8 * j + 16);
+                    g1 = *reinterpret_cast<const f32x4 *>(ga + 8 * j + 24);
+                    w1 = *reinterpret_cast<const f32x4 *>(wb + 8 * j + 24);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0[i], w0[i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1[i], w1[i], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cg0[i], cw0[i], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cg1[i], cw1[i], acc1, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // epilogue: the sixteen z_{l-1} values of the lane come from LDS in one batch (rows past the block's end hold
             // finite filler), everything else is predicated -- no load sits between two stores
@@ -249,24 +272,31 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) zv[e] = z[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
             }
+            // one base pointer per lane, compile-time row offsets: the stores need no per-element address arithmetic
+            float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
+            auto finish = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool ok = rr < valid;
-                float v = acc0[e] + acc1[e] + c_b;
-                if (ADD) v += addv[e];
-                if (YACT) {
-                    if (DROP) {
-                        const uint32_t el = (uint32_t)(trow0 + rr) * (uint32_t)CY + (uint32_t)dcol;
-                        v = (mix32(el ^ a.prev.drop_seed) >= dthr) ? v * dscale : 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = FULL || rr < valid;
+                    float v = acc0[e] + acc1[e] + c_b;
+                    if (ADD) v += addv[e];
+                    if (YACT) {
+                        if (DROP) {
+                            const uint32_t el = (uint32_t)(trow0 + rr) * (uint32_t)CY + (uint32_t)dcol;
+                            v = (mix32(el ^ a.prev.drop_seed) >= dthr) ? v * dscale : 0.f;
+                        }
+                        v = fmaf(zv[e], c_s, c_t) > 0.f ? v : 0.f;
+                        const float vs = ok ? v : 0.f;
+                        s_a += vs;
+                        s_b = fmaf(vs, (zv[e] - c_m) * c_i, s_b);
                     }
-                    v = fmaf(zv[e], c_s, c_t) > 0.f ? v : 0.f;
-                    const float vs = ok ? v : 0.f;
-                    s_a += vs;
-                    s_b = fmaf(vs, (zv[e] - c_m) * c_i, s_b);
+                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
                 }
-                if (ok) a.out[(size_t)(trow0 + rr) * CY + dcol] = v;
-            }
+            };
+            if (valid >= 32) finish(std::true_type{});
+            else finish(std::false_type{});
         }
         if (more && w_role) write_lds(buf ^ 1, nxt);
         __syncthreads();

@@ -24,20 +24,30 @@ pytestmark = pytest.mark.gpu
 
 
 def _check_grads(got, want64, want32, what):
+    """Arbiter = the float64 oracle; yardstick = the float32 evaluation of the SAME oracle (torch on the CPU).  The T-Net FC
+    BatchNorms normalise over only B nearly identical rows, so every fp32 implementation of this model scatters around the
+    float64 gradient by up to a few 1e-2 relative, and WHICH tensor takes the hit depends on rounding details: a tensor passes
+    when it is within 4x its own fp32 noise, or within 1.5x the worst relative fp32 noise torch itself shows on any
+    significant tensor of this case."""
     gtot = float(np.sqrt(sum(float(v.double().pow(2).sum()) for v in want64.values())))
+    rel_floor = 0.0
+    for k, w in want64.items():
+        ref = float(w.norm())
+        if ref >= 1e-3 * gtot:
+            rel_floor = max(rel_floor, float((want32[k].double() - w).norm()) / ref)
     bad = []
     for k, w in want64.items():
         g = got[k].detach().cpu().double().reshape(w.shape)
         err = float((g - w).norm())
         ref = float(w.norm())
         noise = float((want32[k].double() - w).norm())
-        tol = 4.0 * noise + 2e-3 * ref + 1e-5 * gtot
+        tol = max(4.0 * noise, 1.5 * rel_floor * ref) + 2e-3 * ref + 1e-5 * gtot
         if not err <= tol:
             bad.append((k, err, noise, ref))
-    assert not bad, f"{what}: " + "; ".join(f"{k}: err {e:.3e} fp32-noise {n:.3e} |g| {r:.3e}" for k, e, n, r in bad[:8])
+    assert not bad, f"{what} (worst torch-fp32 relative noise {rel_floor:.2e}): " + "; ".join(f"{k}: err {e:.3e} fp32-noise {n:.3e} |g| {r:.3e}" for k, e, n, r in bad[:8])
 
 
-@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160), (64, 2, 64)])
+@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160), (64, 2, 64), (64, 2, 300), (4, 3, 700), (64, 2, 544)])
 def test_encoder_backward_matches_oracle_autograd(synth, params, B, W, N):
     ops = sub("ops")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
@@ -76,8 +86,8 @@ def test_encoder_backward_matches_oracle_autograd(synth, params, B, W, N):
     _check_grads(grads, want[torch.float64], want[torch.float32], "encoder")
 
 
-@pytest.mark.parametrize("drop_p", [0.0, 0.3])
-def test_head_backward_matches_oracle_autograd(synth, params, drop_p):
+@pytest.mark.parametrize("drop_p,npc", [(0.0, [160, 96, 224]), (0.3, [160, 96, 224]), (0.3, [700, 300, 513])])
+def test_head_backward_matches_oracle_autograd(synth, params, drop_p, npc):
     ops = sub("ops")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(7, params.HEAD_PARAMS).items()}
     b = {k: torch.from_numpy(v).cuda() for k, v in synth.make_buffers(7, params.HEAD_BUFFERS).items()}
@@ -85,7 +95,7 @@ def test_head_backward_matches_oracle_autograd(synth, params, drop_p):
     pt = ops.PointerTable(params.HEAD_PARAMS, p, "p")
     bt = ops.PointerTable(params.HEAD_BUFFERS, b, "b")
     gt = ops.PointerTable(params.HEAD_PARAMS, grads, "g")
-    B, W, npc = 4, 3, [160, 96, 224]
+    B, W = 4, 3
     Pp = sum(npc)
     gl = synth.uniform(41, (W, B, 256), 0.0, 2.0)
     lo = synth.uniform(42, (B, Pp, 64), -1.0, 1.0)

@@ -62,7 +62,7 @@ def test_encoder_train_matches_reference_golden(golden, synth, params):
         _close(b[k], g["train_" + k], 1e-4, k)
 
 
-@pytest.mark.parametrize("B,W,N", [(3, 2, 96), (8, 3, 160), (4, 9, 512)])
+@pytest.mark.parametrize("B,W,N", [(3, 2, 96), (8, 3, 160), (4, 9, 512), (16, 2, 544), (8, 2, 300), (4, 2, 1100)])
 def test_encoder_train_slots_match_oracle(synth, params, B, W, N):
     """All B*W windows in one launch sequence == W oracle encoder calls on the B windows of each slot."""
     ops, p, b, pt, bt = _enc_tables(synth, params, 5)
