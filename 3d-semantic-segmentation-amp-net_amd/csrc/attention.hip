@@ -7,6 +7,8 @@
 
 namespace ampnet {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void posenc_tokens_kernel(const float *__restrict__ gl, const float *__restrict__ cent,
                                                            const float *__restrict__ w1, const float *__restrict__ b1,
                                                            const float *__restrict__ w2, const float *__restrict__ b2,
@@ -116,18 +118,22 @@ __global__ __launch_bounds__(HO_ROWS) void head_out_kernel(HeadOut a)
         sSc[tid] = a.scale[tid];
         sSh[tid] = a.shift[tid];
     }
-    // tile load in batches of 8 independent loads (a load -> store -> load chain costs one memory round trip each)
-    for (int e0 = tid; e0 < n * 64; e0 += 8 * HO_ROWS) {
-        float tmp[8];
+    // tile load: 16-byte global loads, eight in flight per thread (a load -> store -> load chain costs one memory round trip
+    // each), scalar LDS writes into the 65-float rows (conflict-free column reads below)
+    for (int e0 = tid; e0 < n * 16; e0 += 8 * HO_ROWS) {
+        f32x4 tmp[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * HO_ROWS;
-            tmp[u] = e < n * 64 ? a.z3[(size_t)row0 * 64 + e] : 0.f;
+            tmp[u] = e < n * 16 ? *reinterpret_cast<const f32x4 *>(a.z3 + (size_t)row0 * 64 + 4 * (size_t)e) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * HO_ROWS;
-            if (e < n * 64) sT[e / 64][e % 64] = tmp[u];
+            if (e < n * 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sT[e / 16][4 * (e % 16) + i] = tmp[u][i];
+            }
         }
     }
     __syncthreads();

@@ -488,19 +488,23 @@ int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
 
 namespace ampnet {
 // dst[p(q)] = src[q]^T with p(q) the slot-major row of window q
-__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots)
+__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots, int chunks)
 {
     __shared__ float t[64][65];
     const int q = blockIdx.x;
     const size_t p = (size_t)(q % n_slots) * (Q / n_slots) + q / n_slots;
-    for (int e = threadIdx.x; e < 4096; e += 256) t[e / 64][e % 64] = src[(size_t)q * 4096 + e];
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) s += src[((size_t)q * chunks + ch) * 4096 + e];     // the window's chunk partials, in order
+        t[e / 64][e % 64] = s;
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < 4096; e += 256) dst[p * 4096 + e] = t[e % 64][e / 64];
 }
 
-int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, hipStream_t st)
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, hipStream_t st)
 {
-    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots);
+    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots, chunks);
     return check_launch("transpose64_kernel");
 }
 }  // namespace ampnet

@@ -68,7 +68,7 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.g1 = c.take<float>(Q * 256);
     w.d_pool = c.take<float>(Q * 256);
     w.dT64 = c.take<float>(Q * 4096);
-    w.dT64t = c.take<float>(Q * 4096);
+    w.dT64t = c.take<float>(Q * (size_t)s.chunks * 4096);     // per (window, chunk) partials of the per-window transform gradient
     w.dWeff = c.take<float>(Q * 576);
     w.dT3 = c.take<float>(Q * 12);
     w.srows = c.take<float>(Q * 256 * 128);
@@ -372,9 +372,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         w.y = e.act(f.z_c2, BN_C2, 64);
         w.dWpart = b.dT64t; w.ldp = 64;
         w.win_off = win_off; w.Q = Q; w.n_slots = n_slots; w.rows_hint = total_rows;
+        w.chunk_rows = e.s.chunk_rows; w.chunks = e.s.chunks;      // several workgroups per window: no half-empty last round
         TRY(pw_wgrad(w, st));
-        // window q's matrix belongs at the slot-major row the forward used for feat_T
-        TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, st));
+        // window q's matrix (sum of its chunk partials) belongs at the slot-major row the forward used for feat_T
+        TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, e.s.chunks, st));
         if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
         PwDgrad d;                                   // d_h[row][k] = sum_j d_local[row][j] * T[k][j]
         d.g = e.dense(b.d_local, nullptr, -1, 64);

@@ -249,12 +249,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; AMPNET_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, with AMPNET_DIST_BACKEND=gloo) folds the ranks onto
+    # the devices that exist
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev if os.environ.get("AMPNET_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("AMPNET_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.mode == "fps":
         return bench_fps(args, dev, rank, world, dist)
