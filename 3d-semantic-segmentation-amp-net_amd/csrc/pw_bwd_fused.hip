@@ -158,6 +158,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         for (int j = 0; j < TYW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc_w[i][j][e] = 0.f;
+    // Gram form at 128 x 128: the matrix is symmetric, so the four W waves own the 10 tiles of its upper triangle
+    // (3, 3, 2, 2) instead of all 16 and mirror them when they flush: 112 instead of 128 MFMAs per SIMD and block of rows
+    constexpr bool SYM = GRAM && CX == 128 && CY == 128;
+    // wave -> (ta, tb) of its tiles, as 4-bit fields: w0 (0,0)(0,1)(1,1)  w1 (0,2)(0,3)(1,2)  w2 (1,3)(2,2)  w3 (2,3)(3,3)
+    const uint32_t sym_a = ww == 0 ? 0x100u : (ww == 1 ? 0x100u : (ww == 2 ? 0x21u : 0x32u));
+    const uint32_t sym_b = ww == 0 ? 0x110u : (ww == 1 ? 0x232u : (ww == 2 ? 0x23u : 0x33u));
+    const int sym_n = ww < 2 ? 3 : 2;
     float wys[TYW], wyt[TYW];
 #pragma unroll
     for (int j = 0; j < TYW; ++j) {
@@ -192,7 +199,33 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         const bool more = advance(nxt);
         if (more && w_role) load_regs(nxt);
         const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
-        if (w_role) {
+        if (w_role && SYM) {
+            float pa_n[3], pb_n[3];
+            auto fetch3 = [&](int s2) {
+                const int kr = 2 * s2 + h;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    pa_n[t] = g[kr * LDG + 32 * (int)((sym_a >> (4 * t)) & 15u) + r];
+                    pb_n[t] = g[kr * LDG + 32 * (int)((sym_b >> (4 * t)) & 15u) + r];
+                }
+            };
+            fetch3(0);
+#pragma unroll 8
+            for (int s2 = 0; s2 < ROWS / 2; ++s2) {
+                float pa[3], pb[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    pa[t] = pa_n[t];
+                    pb[t] = pb_n[t];
+                }
+                if (s2 + 1 < ROWS / 2) fetch3(s2 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[0], pb[0], acc_w[0][0], 0, 0, 0);
+                acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[1], pb[1], acc_w[0][1], 0, 0, 0);
+                if (sym_n == 3) acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2], pb[2], acc_w[1][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (w_role) {
             // software pipeline: the operands of step s2 + 1 are read from LDS before the MFMAs of step s2 issue, so the
             // matrix pipe never waits on an LDS round trip.  Gram form: x and y are the same activated tile (sG).
             float xa_n[TXW], yb_n[TYW];
@@ -306,7 +339,22 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     }
 
     // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
-    if (w_role) {
+    if (w_role && SYM) {
+        float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (t >= sym_n) continue;
+            const int ta = (int)((sym_a >> (4 * t)) & 15u), tb = (int)((sym_b >> (4 * t)) & 15u);
+            const f32x16 &acc = t == 0 ? acc_w[0][0] : (t == 1 ? acc_w[0][1] : acc_w[1][0]);
+            const int cy = 32 * tb + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cx = 32 * ta + (e & 3) + 8 * (e >> 2) + 4 * h;
+                dst[(size_t)cx * CY + cy] = acc[e];
+                if (ta != tb) dst[(size_t)cy * CY + cx] = acc[e];          // the mirrored tile
+            }
+        }
+    } else if (w_role) {
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
 #pragma unroll
         for (int i = 0; i < TXW; ++i)
@@ -383,7 +431,9 @@ static int launch_fused_x(const PwBwd &a, hipStream_t st)
     snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s", CX, CY, a.g.act ? "+gram" : "");
     const double rows = (double)a.rows_hint;
     const bool same = a.g.act && a.g.z == a.prev.z;
-    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * ((a.g.dy ? CX : 0) + ((a.g.P1 || a.g.act) ? CX : 0) + (same ? 0 : CY) + CY + (a.add ? CY : 0)), st);
+    // flops the launch executes: the symmetric Gram form multiplies 10 of the 16 tiles
+    const double wflops = (GRAM && CX == 128 && CY == 128) ? 2.0 * rows * CX * CY * 10.0 / 16.0 : 2.0 * rows * CX * CY;
+    ProfScope prof(name, wflops + 2.0 * rows * CX * CY, rows * 4.0 * ((a.g.dy ? CX : 0) + ((a.g.P1 || a.g.act) ? CX : 0) + (same ? 0 : CY) + CY + (a.add ? CY : 0)), st);
     hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(FB_THREADS), lds, st, a);
     return check_launch("pw_bwd_kernel");
 }
