@@ -71,20 +71,21 @@ def profile_read():
     return out
 
 
-def pmc_traffic_for(name):
+def pmc_traffic_for(name, rows=None):
     """HBM bytes per launch (read + write) of the kernel bench.py calls `name`, from the rocprofv3 PMC passes summarised
     in profiles/pmc_traffic.json (profiles/pmc_traffic.py; FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact).  None when the
     file or an unambiguous match is missing."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
-    v = json.load(open(path)).get("events", {}).get(name)
-    if not v:
-        return None
+    table = json.load(open(path))
+    v = table.get("events", {}).get(name)
+    if not v or (rows is not None and table.get("workload_rows") != rows):
+        return None                                     # the counters were collected on a different batch
     return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
 
 
-def roofline_from(rows):
+def roofline_from(rows, work_rows=None):
     if not rows:
         return None
     top = max(rows, key=lambda r: r["ms"])
@@ -95,12 +96,12 @@ def roofline_from(rows):
     if intensity >= peak_tf * 1e3 / PEAK_HBM_GBPS:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s",
-                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"]),
+                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"], work_rows),
                     algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
                     launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=pmc_traffic_for(top["name"]), launch_ms=round(per_ms, 4), launches=int(top["calls"]),
+                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=pmc_traffic_for(top["name"], work_rows), launch_ms=round(per_ms, 4), launches=int(top["calls"]),
                 share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
 
 
@@ -381,7 +382,7 @@ def main():
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "bf16_forward_mode": bf16_leg,
-            "roofline": roofline_from(rows),
+            "roofline": roofline_from(rows, B * N_WIN * N_POINTS),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))
                                for r in rows], key=lambda r: -r["ms_per_step"])[:args.kernels],

@@ -26,7 +26,7 @@ def per_dispatch(dirname, counter):
     return out
 
 
-def main(src, dst):
+def main(src, dst, rows_per_launch=64 * 9 * 2048):
     fe, wr = per_dispatch(src, "FETCH_SIZE"), per_dispatch(src, "WRITE_SIZE")
     res = {}
     for sym, rows in fe.items():
@@ -53,9 +53,10 @@ def main(src, dst):
         if name and (name not in events or int(grid) > events[name]["grid"]):
             events[name] = dict(v, grid=int(grid), symbol=sym)
     res["events"] = events
+    res["workload_rows"] = rows_per_launch          # rows (points) every point-layer launch of the profiled step processes
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
-    print(f"wrote {dst}: {len(res) - 1} (kernel, grid) entries, {len(events)} bench event names")
+    print(f"wrote {dst}: {len(res) - 2} (kernel, grid) entries, {len(events)} bench event names")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *(int(a) for a in sys.argv[3:4]))
