@@ -8,6 +8,8 @@ in a Python loop with 9 H2D copies, a repeat/cat loop and a CPU argmax; here the
 in one copy, all B*W windows run through one encoder launch sequence with per-slot BatchNorm statistics,
 the head never materialises the 320-channel tensor, and loss + argmax are fused into the last kernel.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -38,6 +40,43 @@ def augment_batch(pc_clusters, targets, train):
             np.random.shuffle(idx)
             x[:, w] = x[:, w][:, idx]
             t[:, w] = t[:, w][:, idx]
+    return x, t
+
+
+def augment_batch_device(pc_clusters, targets, train, device):
+    """augment_batch on the GPU (include/ampnet_hip.h: ampnet_augment_f32): the collated batch goes up in one copy and one
+    kernel applies cluster permutation, z-rotation (float64, as numpy computes it), the per-window point permutations and the
+    re-layout.  The draws come from numpy's global RNG in the reference's order -- cluster permutation, angle, then (train
+    only) one point permutation per window -- so a seeded run sees the same batch as augment_batch / the reference.
+    pc_clusters [B, N, 9, W], targets [B, N, W] (host or device tensors) -> device x [B, W, N, 9] f32, t [B, W, N] i64."""
+    import ctypes
+    pc = torch.as_tensor(pc_clusters)
+    tg = torch.as_tensor(targets)
+    B, N, D, W = pc.shape
+    if D != 9 or pc.dtype != torch.float32 or tg.dtype != torch.int64 or tuple(tg.shape) != (B, N, W):
+        raise _lib.AmpnetError(f"augment_batch_device: expected pc [B, N, 9, W] f32 and targets [B, N, W] i64, got {tuple(pc.shape)} {pc.dtype} / {tuple(tg.shape)} {tg.dtype}")
+    cperm = np.arange(W)
+    np.random.shuffle(cperm)                                   # shuffle_clusters
+    r_angle = np.random.uniform() * 2 * np.pi
+    pperm = None
+    if train:
+        pperm = np.empty((W, N), dtype=np.int32)
+        for w in range(W):                                     # shuffle_data: one permutation per window
+            idx = np.arange(N)
+            np.random.shuffle(idx)
+            pperm[w] = idx
+    dev = torch.device(device)
+    pcd = pc.to(dev, non_blocking=True).contiguous()
+    tgd = tg.to(dev, non_blocking=True).contiguous()
+    cpd = torch.from_numpy(cperm.astype(np.int32)).to(dev, non_blocking=True)
+    ppd = torch.from_numpy(pperm).to(dev, non_blocking=True) if pperm is not None else None
+    x = torch.empty((B, W, N, 9), dtype=torch.float32, device=dev)
+    t = torch.empty((B, W, N), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_augment_f32(_lib.ptr(pcd), _lib.ptr(tgd), _lib.ptr(cpd), _lib.ptr(ppd),
+                                           ctypes.c_double(float(np.cos(r_angle))), ctypes.c_double(float(np.sin(r_angle))),
+                                           1 if train else 0, B, N, W, _lib.ptr(x), _lib.ptr(t), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_augment_f32")
     return x, t
 
 
@@ -85,8 +124,11 @@ def train_loop(data, optimizer_pointnet, optimizer_att, ce_loss, pointnet, att_n
     optimizer_att.zero_grad()
     pointnet.train(train)
     att_net.train(train)
-    x, t = augment_batch(pc_clusters, targets, train)
     dev = next(pointnet.parameters()).device
+    if os.environ.get("AMPNET_HOST_AUG") == "1":
+        x, t = augment_batch(pc_clusters, targets, train)            # the numpy path (same draws, same batch)
+    else:
+        x, t = augment_batch_device(pc_clusters, targets, train, dev)
     cw = _class_weights(ce_loss, dev)
     metrics = {}
     if train:
@@ -99,4 +141,4 @@ def train_loop(data, optimizer_pointnet, optimizer_att, ce_loss, pointnet, att_n
     metrics['ce_loss'] = out["ce"][0].view(-1, 1)
     metrics['reg_loss'] = out["reg"]
     metrics['loss'] = metrics['ce_loss'] + 0.001 * metrics['reg_loss'] if train else metrics['ce_loss']
-    return metrics, out["targets_pc"], out["preds"].cpu(), last_epoch
+    return metrics, out["targets_pc"].cpu(), out["preds"].cpu(), last_epoch

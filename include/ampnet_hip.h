@@ -159,6 +159,16 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- a8 on the device: the input pipeline of train_loop in one kernel --------------------------------------------
+ * replaces the host augmentation of train_pointnet-attention.py:390-405 (shuffle_clusters utils/utils.py:620-632,
+ * rotate_point_cloud_z :582-604, shuffle_data :607-617) and the [B, N, 9, W] -> [B, W, N, 9] re-layout.
+ *   pc [B, N, 9, W] float32 and targets [B, N, W] int64 (may be NULL with t_out) as collate_seq_padd returns them, on the device
+ *   cluster_perm [W], point_perm [W, N] (NULL = identity) int32 on the device: x_out[b, w, n] = pc[b, point_perm[w, n], :, cluster_perm[w]]
+ *   rotate != 0: (x, y, z) <- (x c - y s, x s + y c, z) in float64, rounded to float32 (numpy's float64 dot of the reference)
+ *   x_out [B, W, N, 9], t_out [B, W, N]                                                                         */
+int ampnet_augment_f32(const float *pc, const long long *targets, const int32_t *cluster_perm, const int32_t *point_perm,
+                       double cos_a, double sin_a, int rotate, int B, int N, int W, float *x_out, long long *t_out, void *stream);
+
 /* ---- k-NN grouping of FPS centres (BUILD-DEFINED; BASELINE.json north_star / config 5) ------------------------------
  * The reference has no k-NN or ball query: nothing is replaced, parity against it is "unpinned"; the spec
  * below is pinned by oracle/fps_oracle.py:knn_indices.
