@@ -76,7 +76,6 @@ def head_apply(module, pt, bt, gl_rows, lo_rows, centroids, off, mask, B, W, tot
     cent = centroids.to(gl_rows.device).float().contiguous()
     logits = _HeadFn.apply((module, pt, bt, cent, off, mask, B, W, total, mx, n_classes, p_drop, seed),
                            gl_rows.contiguous().float(), lo_rows.contiguous().float(), *params)
-    module.bn_2.num_batches_tracked += 1
-    module.bn_3.num_batches_tracked += 1
+    torch._foreach_add_([module.bn_2.num_batches_tracked, module.bn_3.num_batches_tracked], 1)
     preds = logits.detach().argmax(dim=1) if want_preds else None
     return logits, preds, None

@@ -134,9 +134,8 @@ class BasePointNet(nn.Module):
         return self._cache.get(self, P.ENC_PARAMS, P.ENC_BUFFERS, "BasePointNet")
 
     def _bump_batches(self, n):
-        for m in self.modules():
-            if isinstance(m, _BN):
-                m.num_batches_tracked += n
+        # one multi-tensor launch for the 16 counters (16 single-element kernels per step otherwise)
+        torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)], n)
 
     def forward_windows(self, x, np_cluster=None, n_slots=1):
         """All windows of a step in one launch sequence.
@@ -230,8 +229,7 @@ class SegmentationWithAttention(nn.Module):
         out = ops.head_forward(pt, bt, gl_rows, lo_rows, centroids, off, attn_mask, B, W, total, mx, self.num_classes,
                                train, self.p_drop, seed, self._ws, targets=targets, class_w=class_w, want_preds=want_preds)
         if train:
-            self.bn_2.num_batches_tracked += 1
-            self.bn_3.num_batches_tracked += 1
+            torch._foreach_add_([self.bn_2.num_batches_tracked, self.bn_3.num_batches_tracked], 1)
         return out
 
     def forward(self, gl_feats, lo_feats, centroids, np_cluster, attn_mask=None):

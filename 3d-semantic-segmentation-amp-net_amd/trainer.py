@@ -131,8 +131,7 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     att_net._step += 1
     logits, preds, loss2 = ops.head_forward(hpt, hbt, glob, local, cent, off, mask, B, W, total, mx, att_net.num_classes, True,
                                             att_net.p_drop, seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
-    att_net.bn_2.num_batches_tracked += 1
-    att_net.bn_3.num_batches_tracked += 1
+    torch._foreach_add_([att_net.bn_2.num_batches_tracked, att_net.bn_3.num_batches_tracked], 1)
     feat_last = feat_T[-B:]
     reg, G = ops.reg_loss(feat_last, keep_G=True)
     # ---- backward ----
