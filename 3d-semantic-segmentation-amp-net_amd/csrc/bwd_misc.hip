@@ -650,27 +650,166 @@ int sparse_fix(const SparseFix &a, hipStream_t st)
     return check_launch("sparse_fix_kernel");
 }
 
-// one thread per (j, k) of G (and row j == cp for c0), loop over the C contracted channels
+// ----------------------------------------------------------------------------------------------------
+// sparse_scatter = sparse_rows + sparse_fix without the [Q * C, cp] intermediate: one workgroup per window finds, for every
+// distinct argmax row, the chain of channels that picked it (channel order, so the sums are reproducible), and adds
+//   out[row][k] += mask(row, k) * sum_chain P1[c] dpm[c] W[c][k]
+// together with that window's share of the BatchNorm-backward sums.  Eight rows per trip, all loads before the first use.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void sparse_scatter_kernel(SparseScatter a)
+{
+    __shared__ int sArg[256], sOwn[256], sNext[256];
+    __shared__ float sCoef[256];
+    __shared__ int s_wave_cnt[8];
+    __shared__ float sRed[4][2][128];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+    const int prow = a.slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+    const int c = tid;                                        // C <= 256; threads 256..511 only join the row loop
+    int r = -1;
+    if (c < a.C) r = a.arg[(size_t)q * a.C + c];
+    if (c < 256) {
+        sArg[c] = r;
+        sCoef[c] = r >= 0 ? a.P1[(size_t)slot * a.C + c] * a.dpm[(size_t)prow * a.C + c] : 0.f;
+        sNext[c] = -1;
+    }
+    __syncthreads();
+    // pred = the closest lower channel with the same argmax row (none: this channel owns the row)
+    int pred = -1;
+    if (r >= 0 && c < 256) {
+        for (int p = c - 1; p >= 0; --p)
+            if (sArg[p] == r) {
+                pred = p;
+                break;
+            }
+    }
+    const bool owner = r >= 0 && pred < 0;
+    if (pred >= 0) sNext[pred] = c;                           // every channel has at most one successor
+    const unsigned long long bo = __ballot(owner);
+    if (lane == 0) s_wave_cnt[wv] = __popcll(bo);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += s_wave_cnt[w];
+    const int n_own = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];      // waves 4..7 own nothing
+    if (owner) sOwn[base + __popcll(bo & ((1ull << lane) - 1ull))] = c;      // owners in channel order
+    __syncthreads();
+
+    const int k = tid & 127, grp = tid >> 7;                 // four row groups x cp columns
+    float sa = 0.f, sb = 0.f;
+    if (k < a.cp) {
+        const float sc = a.s_prev[(size_t)slot * a.cp + k], sh = a.t_prev[(size_t)slot * a.cp + k];
+        const float mu = a.mean_prev[(size_t)slot * a.cp + k], is = a.invstd_prev[(size_t)slot * a.cp + k];
+        for (int i0 = grp; i0 < n_own; i0 += 32) {
+            int ch[8], rowv[8];
+            float wv8[8], zv[8], ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + 4 * u, n_own - 1);
+                ch[u] = sOwn[i];
+                rowv[u] = sArg[ch[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                wv8[u] = a.W[(size_t)ch[u] * a.cp + k];
+                zv[u] = a.z_prev[(size_t)rowv[u] * a.cp + k];
+                ov[u] = a.out[(size_t)rowv[u] * a.cp + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + 4 * u >= n_own) continue;
+                float sv = sCoef[ch[u]] * wv8[u];
+                for (int cc = sNext[ch[u]]; cc >= 0; cc = sNext[cc]) sv = fmaf(sCoef[cc], a.W[(size_t)cc * a.cp + k], sv);   // merged channels (rare)
+                const float v = fmaf(zv[u], sc, sh) > 0.f ? sv : 0.f;
+                a.out[(size_t)rowv[u] * a.cp + k] = ov[u] + v;            // distinct rows: no conflict
+                sa += v;
+                sb = fmaf(v, (zv[u] - mu) * is, sb);
+            }
+        }
+    }
+    sRed[grp][0][k] = sa;
+    sRed[grp][1][k] = sb;
+    __syncthreads();
+    if (grp == 0 && k < a.cp) {
+        const size_t o = (size_t)(q * a.part_chunks + a.slot_idx) * a.cp + k;
+        a.part_a[o] = (sRed[0][0][k] + sRed[1][0][k]) + (sRed[2][0][k] + sRed[3][0][k]);
+        a.part_b[o] = (sRed[0][1][k] + sRed[1][1][k]) + (sRed[2][1][k] + sRed[3][1][k]);
+    }
+}
+
+int sparse_scatter(const SparseScatter &a, hipStream_t st)
+{
+    AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.z_prev && a.s_prev && a.t_prev && a.mean_prev && a.invstd_prev && a.out && a.part_a && a.part_b,
+                   "sparse_scatter: null pointer");
+    AMPNET_REQUIRE(a.cp <= 128 && a.C <= 256, "sparse_scatter: C=%d cp=%d", a.C, a.cp);
+    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(a.Q), dim3(512), 0, st, a);
+    return check_launch("sparse_scatter_kernel");
+}
+
+// workgroup = (16 rows j of G[slot] | the c0 row, slot): W streams through LDS once per workgroup in chunks of 32 channels
+// (the next chunk's loads are in flight while the current one is multiplied), thread = column k x 8 of the 16 rows
+constexpr int SM_J = 16, SM_C = 32;
+
 __global__ __launch_bounds__(256) void slot_mats_kernel(const float *__restrict__ W, const float *__restrict__ P2, const float *__restrict__ P3,
                                                        int C, int cp, float *__restrict__ G, float *__restrict__ c0)
 {
-    const int s = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= (cp + 1) * cp) return;
-    const int j = e / cp, k = e % cp;
-    float acc = 0.f;
-    if (j < cp) {
-        for (int c = 0; c < C; ++c) acc = fmaf(W[(size_t)c * cp + j] * P2[(size_t)s * C + c], W[(size_t)c * cp + k], acc);
-        G[((size_t)s * cp + j) * cp + k] = acc;
+    __shared__ float sWk[SM_C][128], sWj[SM_C][SM_J];
+    const int s = blockIdx.y, jb = blockIdx.x, tid = threadIdx.x;
+    const bool c0_block = jb * SM_J >= cp;
+    const int j0 = jb * SM_J;
+    const int k = tid & 127, jg = tid >> 7;                     // rows j0 + 8 jg .. + 7
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    // staging roles: 16 floats of the chunk per thread; chunk element e = c * cp + kk
+    float rw[16];
+    auto fetch = [&](int cbase) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i, cc = e / 128, kk = e % 128;
+            rw[i] = (kk < cp && cbase + cc < C) ? W[(size_t)(cbase + cc) * cp + kk] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int cbase = 0; cbase < C; cbase += SM_C) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = tid + 256 * i;
+            sWk[e / 128][e % 128] = rw[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < SM_C * SM_J; e += 256) {
+            const int cc = e / SM_J, jj = e % SM_J, c = cbase + cc;
+            float v = 0.f;
+            if (c < C) {
+                if (c0_block) v = jj == 0 ? P3[(size_t)s * C + c] : 0.f;
+                else v = (j0 + jj < cp) ? sWk[cc][j0 + jj] * P2[(size_t)s * C + c] : 0.f;
+            }
+            sWj[cc][jj] = v;
+        }
+        if (cbase + SM_C < C) fetch(cbase + SM_C);
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < SM_C; ++cc) {
+            const float wk = sWk[cc][k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(sWj[cc][8 * jg + i], wk, acc[i]);
+        }
+    }
+    if (k >= cp) return;
+    if (c0_block) {
+        if (jg == 0) c0[(size_t)s * cp + k] = acc[0];
     } else {
-        for (int c = 0; c < C; ++c) acc = fmaf(P3[(size_t)s * C + c], W[(size_t)c * cp + k], acc);
-        c0[(size_t)s * cp + k] = acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (j0 + 8 * jg + i < cp) G[((size_t)s * cp + j0 + 8 * jg + i) * cp + k] = acc[i];
     }
 }
 
 int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st)
 {
-    hipLaunchKernelGGL(slot_mats_kernel, dim3(cdiv((cp + 1) * cp, 256), n_slots), dim3(256), 0, st, W, P2, P3, C, cp, G, c0);
+    AMPNET_REQUIRE(W && P2 && P3 && G && c0 && cp >= 1 && cp <= 128 && C >= 1, "slot_mats: bad arguments (cp=%d)", cp);
+    hipLaunchKernelGGL(slot_mats_kernel, dim3(cdiv(cp, SM_J) + 1, n_slots), dim3(256), 0, st, W, P2, P3, C, cp, G, c0);
     return check_launch("slot_mats_kernel");
 }
 

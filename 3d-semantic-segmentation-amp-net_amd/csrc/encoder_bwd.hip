@@ -211,10 +211,12 @@ struct EncBwd {
         p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.C = 256;
         p.dpm = b.dpm; p.P1 = b.bn[bn].P1; p.P2 = b.bn[bn].P2; p.P3 = b.bn[bn].P3; p.slot_ab = b.bn[bn].slot_ab;
         TRY(pool_bwd(p, st));
-        SparseRows sr;
-        sr.arg = arg; sr.dpm = b.dpm; sr.slot_major = slot_major; sr.P1 = b.bn[bn].P1; sr.W = W;
-        sr.Q = s.Q; sr.n_slots = s.n_slots; sr.srows = b.srows; sr.srow_row = b.srow_row; sr.srow_cnt = b.srow_cnt;
-        TRY(sparse_rows(sr, st));
+        if (!fused) {
+            SparseRows sr;
+            sr.arg = arg; sr.dpm = b.dpm; sr.slot_major = slot_major; sr.P1 = b.bn[bn].P1; sr.W = W;
+            sr.Q = s.Q; sr.n_slots = s.n_slots; sr.srows = b.srows; sr.srow_row = b.srow_row; sr.srow_cnt = b.srow_cnt;
+            TRY(sparse_rows(sr, st));
+        }
         TRY(slot_mats(W, b.bn[bn].P2, b.bn[bn].P3, s.n_slots, 256, 128, b.Gm, b.c0, st));
         PooledWgrad pw;
         pw.W = W; pw.P1 = b.bn[bn].P1; pw.P2 = b.bn[bn].P2; pw.P3 = b.bn[bn].P3; pw.gram = b.gram; pw.asum = b.asum;
@@ -242,9 +244,14 @@ struct EncBwd {
             TRY(reduce_slots(b.dbpart, nblk, 1, s.n_slots, 128, b.asum, st));
             TRY(pooled_wgrad(pw, st));
             // the scattered rows: added after the dense part, their share of the sums goes behind the workgroup partials
-            sf.part_a = f.part_sum + (size_t)nblk * 128; sf.part_b = f.part_sq + (size_t)nblk * 128;
-            sf.part_chunks = 1; sf.slot_idx = 0;
-            TRY(sparse_fix(sf, st));
+            SparseScatter ss;
+            ss.arg = arg; ss.dpm = b.dpm; ss.slot_major = slot_major; ss.P1 = b.bn[bn].P1; ss.W = W;
+            ss.z_prev = z_prev; ss.s_prev = f.bn[prev_bn].scale; ss.t_prev = f.bn[prev_bn].shift;
+            ss.mean_prev = f.bn[prev_bn].mean; ss.invstd_prev = f.bn[prev_bn].invstd;
+            ss.Q = s.Q; ss.n_slots = s.n_slots; ss.out = dy_out;
+            ss.part_a = f.part_sum + (size_t)nblk * 128; ss.part_b = f.part_sq + (size_t)nblk * 128;
+            ss.part_chunks = 1; ss.slot_idx = 0;
+            TRY(sparse_scatter(ss, st));
             return finalize_prev(prev_bn, 128, nblk + s.Q, 1);
         }
         // Gram and column sums of a = relu(bn_prev(z_prev)) per slot, then dW

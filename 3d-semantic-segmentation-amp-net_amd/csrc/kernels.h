@@ -304,6 +304,19 @@ struct SparseFix {
     int part_chunks = 1, slot_idx = 0;
 };
 int sparse_fix(const SparseFix &a, hipStream_t st);
+// sparse_rows + sparse_fix in one kernel, no [Q * C, cp] intermediate (the fused backward uses this one)
+struct SparseScatter {
+    const int *arg = nullptr;           // [Q, C]
+    const float *dpm = nullptr;         // [Q, C]
+    int slot_major = 0;
+    const float *P1 = nullptr, *W = nullptr;   // [n_slots, C], [C, cp]
+    const float *z_prev = nullptr, *s_prev = nullptr, *t_prev = nullptr, *mean_prev = nullptr, *invstd_prev = nullptr;
+    int Q = 0, n_slots = 1, C = 256, cp = 128;
+    float *out = nullptr;               // [rows, cp]
+    float *part_a = nullptr, *part_b = nullptr;
+    int part_chunks = 1, slot_idx = 0;
+};
+int sparse_scatter(const SparseScatter &a, hipStream_t st);
 // G[s][j][k] = sum_c W[c][j] P2[s][c] W[c][k];  c0[s][k] = sum_c P3[s][c] W[c][k]
 int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st);
 // out[s][e] = sum over windows q = s (mod n_slots), chunks: part[(q * chunks + ch) * n_el + e]
