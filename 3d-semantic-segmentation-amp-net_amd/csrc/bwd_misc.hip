@@ -288,38 +288,76 @@ int fc_act(const float *z, const float *s, const float *t, int rows, int C, int 
 }
 
 // da [rows, C] = grad wrt relu(bn(z)); block = (slot, 64 channels): full BatchNorm backward over the slot's `per` rows
-__global__ __launch_bounds__(64) void fc_bn_bwd_kernel(const float *__restrict__ da, const float *__restrict__ z,
-                                                      const float *__restrict__ scale, const float *__restrict__ shift,
-                                                      const float *__restrict__ mean, const float *__restrict__ invstd, int per, int C,
-                                                      float *__restrict__ g, float *__restrict__ slot_ab)
+constexpr int FCB_G = 8;       // row groups per channel (block = 64 channels x 8 groups)
+
+__global__ __launch_bounds__(64 * FCB_G) void fc_bn_bwd_kernel(const float *__restrict__ da, const float *__restrict__ z,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd, int per, int C,
+                                                              float *__restrict__ g, float *__restrict__ slot_ab)
 {
-    const int s = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
-    if (c >= C) return;
-    const size_t so = (size_t)s * C + c;
+    __shared__ double rA[FCB_G][64], rB[FCB_G][64];
+    const int s = blockIdx.x, cl = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.y * 64 + cl;
+    const bool ok = c < C;
+    const size_t so = (size_t)s * C + (ok ? c : 0);
     const float sc = scale[so], sh = shift[so], mu = mean[so], is = invstd[so];
     double A = 0.0, Bs = 0.0;
-    for (int i = 0; i < per; ++i) {
-        const size_t o = (size_t)(s * per + i) * C + c;
-        const float zv = z[o];
-        const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
-        A += (double)dy;
-        Bs += (double)dy * (double)((zv - mu) * is);
+    // eight rows per trip, their sixteen loads in flight together (a dependent chain of 2 * per loads otherwise)
+    for (int i0 = grp; i0 < per; i0 += FCB_G * 8) {
+        float zv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + FCB_G * u;
+            const bool live = ok && i < per;
+            const size_t o = (size_t)(s * per + (live ? i : 0)) * C + (ok ? c : 0);
+            zv[u] = live ? z[o] : 0.f;
+            dv[u] = live ? da[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float dy = fmaf(zv[u], sc, sh) > 0.f ? dv[u] : 0.f;      // dead rows: dv = 0
+            A += (double)dy;
+            Bs += (double)dy * (double)((zv[u] - mu) * is);
+        }
+    }
+    rA[grp][cl] = A;
+    rB[grp][cl] = Bs;
+    __syncthreads();
+    A = 0.0;
+    Bs = 0.0;
+#pragma unroll
+    for (int k = 0; k < FCB_G; ++k) {
+        A += rA[k][cl];
+        Bs += rB[k][cl];
     }
     const float an = (float)(A / per), bn = (float)(Bs / per);
-    for (int i = 0; i < per; ++i) {
-        const size_t o = (size_t)(s * per + i) * C + c;
-        const float zv = z[o];
-        const float dy = fmaf(zv, sc, sh) > 0.f ? da[o] : 0.f;
-        g[o] = sc * (dy - an - (zv - mu) * is * bn);
+    for (int i0 = grp; i0 < per; i0 += FCB_G * 8) {
+        float zv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + FCB_G * u;
+            const bool live = ok && i < per;
+            const size_t o = (size_t)(s * per + (live ? i : 0)) * C + (ok ? c : 0);
+            zv[u] = live ? z[o] : 0.f;
+            dv[u] = live ? da[o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + FCB_G * u;
+            if (!(ok && i < per)) continue;
+            const float dy = fmaf(zv[u], sc, sh) > 0.f ? dv[u] : 0.f;
+            g[(size_t)(s * per + i) * C + c] = sc * (dy - an - (zv[u] - mu) * is * bn);
+        }
     }
-    slot_ab[so * 2 + 0] = (float)A;
-    slot_ab[so * 2 + 1] = (float)Bs;
+    if (grp == 0 && ok) {
+        slot_ab[so * 2 + 0] = (float)A;
+        slot_ab[so * 2 + 1] = (float)Bs;
+    }
 }
 
 int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *shift, const float *mean, const float *invstd,
               int n_slots, int per, int C, float *g, float *slot_ab, hipStream_t st)
 {
-    hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(n_slots, cdiv(C, 64)), dim3(64), 0, st, da, z, scale, shift, mean, invstd, per, C, g, slot_ab);
+    hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(n_slots, cdiv(C, 64)), dim3(64 * FCB_G), 0, st, da, z, scale, shift, mean, invstd, per, C, g, slot_ab);
     return check_launch("fc_bn_bwd_kernel");
 }
 
@@ -426,20 +464,32 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
         float s[12];
 #pragma unroll
         for (int f = 0; f < 12; ++f) s[f] = 0.f;
-        for (int q = g; q < Q; q += 4) {
-            const float *e = dWeff + ((size_t)q * 64 + c) * 9;
-            float ev[9];
+        // four windows per trip: their loads (9 gradient values, 9 transform entries each) are issued before the first use
+        for (int q0 = g; q0 < Q; q0 += 16) {
+            float ev[4][9], tv[4][9];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) ev[f] = e[f];
-            if (mode == 0) {
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 4 * u;
+                const bool live = q < Q;
+                const float *e = dWeff + ((size_t)(live ? q : 0) * 64 + c) * 9;
+                const int p = slot_major ? ((live ? q : 0) % n_slots) * (Q / n_slots) + (live ? q : 0) / n_slots : (live ? q : 0);
 #pragma unroll
-                for (int f = 0; f < 3; ++f) s[f] += ev[f];
-            } else {
-                const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
+                for (int f = 0; f < 9; ++f) {
+                    ev[u][f] = live ? e[f] : 0.f;
+                    tv[u][f] = (live && mode != 0) ? T[p * 9 + f] : 0.f;
+                }
+            }
 #pragma unroll
-                for (int f = 0; f < 9; ++f) s[3 + f] += ev[f];
+            for (int u = 0; u < 4; ++u) {
+                if (mode == 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) s[d] += T[p * 9 + 0 * 3 + d] * ev[0] + T[p * 9 + 1 * 3 + d] * ev[1] + T[p * 9 + 2 * 3 + d] * ev[2];
+                    for (int f = 0; f < 3; ++f) s[f] += ev[u][f];
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) s[3 + f] += ev[u][f];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s[d] += tv[u][0 * 3 + d] * ev[u][0] + tv[u][1 * 3 + d] * ev[u][1] + tv[u][2 * 3 + d] * ev[u][2];
+                }
             }
         }
 #pragma unroll
