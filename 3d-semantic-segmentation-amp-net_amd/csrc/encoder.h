@@ -38,6 +38,7 @@ struct EncWs {
     int *arg_t, *arg_f, *arg_c;        // [Q, 256] row index of the pooled extreme
     float *zext_t, *zext_f, *zext_c;   // [Q, 256] its pre-BatchNorm value (all the backward needs of the 256-channel layers)
     int *fc_off;                       // [n_slots + 1]
+    float *merge;                      // two-stage bn_finalize scratch
     float *part_sum, *part_sq, *part_max;   // [Q * chunks, 256]
     int *part_amax;
     BnSlot bn[BN_ENC_COUNT];

@@ -89,6 +89,7 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.zext_f = c.take<float>(Q * 256);
     ws.zext_c = c.take<float>(Q * 256);
     ws.fc_off = c.take<int>((size_t)s.n_slots + 1);
+    ws.merge = c.take<float>(bn_finalize_merge_floats(s.n_slots, 256));     // two-stage bn_finalize scratch
     const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
     // the fused backward indexes its BatchNorm sums by workgroup (<= 256 + n_slots of them) + one row per window
     const size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256;
@@ -180,6 +181,7 @@ struct EncRun {
         f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
         f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;
         f.stat_mean = ws.bn[bn].smean; f.stat_uvar = ws.bn[bn].suvar;
+        f.merge_ws = ws.merge;
         return bn_finalize(f, st);
     }
     int pool(int bn, float *pooled, int *arg, float *zext, bool slot_major) const

@@ -220,7 +220,7 @@ int bn_finalize(const BnFinalize &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.part_sum && a.part_sq && (a.win_off || a.part_rows) && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
     const long per_slot_parts = (long)((a.Q + a.n_slots - 1) / a.n_slots) * a.chunks;
-    if (a.merge_ws && per_slot_parts > 1024 && a.n_slots * FIN_V <= a.Q) {
+    if (a.merge_ws && per_slot_parts >= 128 && a.n_slots * FIN_V <= a.Q) {
         // few slots, thousands of partials each (the head: one slot): merge FIN_V sub-slots per slot on FIN_V x more
         // workgroups first, then finalize those
         const int V = a.n_slots * FIN_V;
