@@ -1,8 +1,8 @@
 // attention.hip -- the small kernels of SegmentationWithAttention (pointNet/model/pointnetAtt.py:176-209):
 // positional encoding (:183-185), the per-(sample, head) attention core of nn.MultiheadAttention(256, 8)
-// (:187-190; sequence = the W <= 32 cluster tokens of one sample, head_dim 32) and the output layer conv_4
-// (:207) with the loss recipe of train_pointnet-attention.py:138,445-450 fused (weighted CE partials, argmax).
-// The in/out projections and conv_2/conv_3 run on pw_gemm (head.hip).
+// (:187-190; sequence = the W <= 32 cluster tokens of one sample, head_dim 32) and the tail of the output layer (:207):
+// transposed logits store, argmax and the loss recipe of train_pointnet-attention.py:138,445-450 (weighted CE partials).
+// The in/out projections and conv_2 / conv_3 / conv_4 run on pw_gemm (head.hip).
 #include "head.h"
 
 namespace ampnet {
@@ -102,56 +102,21 @@ int attention_core(const float *qkv, const uint8_t *key_pad_mask, float *probs, 
 }
 
 // ----------------------------------------------------------------------------------------------------
-constexpr int HO_ROWS = 128;
+// head_logits: the tail of the head once conv_4 itself has run on the matrix cores (pw_gemm<64,32> with the bn_3 + ReLU +
+// dropout prologue, z4 [R, ldz4]): transposed logits store [B, C, P], argmax, weighted cross-entropy partials.
+// thread = row; a workgroup's 256 rows are consecutive points of one sample (or straddle two: handled per row).
+// ----------------------------------------------------------------------------------------------------
+constexpr int HL_ROWS = 256;
 
-__global__ __launch_bounds__(HO_ROWS) void head_out_kernel(HeadOut a)
+__global__ __launch_bounds__(HL_ROWS) void head_logits_kernel(HeadOut a, const float *__restrict__ z4, int ldz4)
 {
-    __shared__ float sT[HO_ROWS][65];
-    __shared__ float sW[HEAD_MAX_CLASSES][64], sB[HEAD_MAX_CLASSES], sSc[64], sSh[64];
-    __shared__ float red[HO_ROWS / 64][2];
-    const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * HO_ROWS;
-    const int n = min(HO_ROWS, a.R - row0);
-    for (int e = tid; e < a.C * 64; e += HO_ROWS) sW[e / 64][e % 64] = a.W[e];
-    if (tid < a.C) sB[tid] = a.bias[tid];
-    if (tid < 64) {
-        sSc[tid] = a.scale[tid];
-        sSh[tid] = a.shift[tid];
-    }
-    // tile load: 16-byte global loads, eight in flight per thread (a load -> store -> load chain costs one memory round trip
-    // each), scalar LDS writes into the 65-float rows (conflict-free column reads below)
-    for (int e0 = tid; e0 < n * 16; e0 += 8 * HO_ROWS) {
-        f32x4 tmp[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * HO_ROWS;
-            tmp[u] = e < n * 16 ? *reinterpret_cast<const f32x4 *>(a.z3 + (size_t)row0 * 64 + 4 * (size_t)e) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * HO_ROWS;
-            if (e < n * 16) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sT[e / 16][4 * (e % 16) + i] = tmp[u][i];
-            }
-        }
-    }
-    __syncthreads();
+    __shared__ float red[HL_ROWS / 64][2];
+    const int tid = threadIdx.x, row = blockIdx.x * HL_ROWS + tid;
     float wnll = 0.f, wsum = 0.f;
-    if (tid < n) {
-        const int row = row0 + tid;
+    if (row < a.R) {
         float acc[HEAD_MAX_CLASSES];
 #pragma unroll
-        for (int c = 0; c < HEAD_MAX_CLASSES; ++c) acc[c] = c < a.C ? sB[c] : 0.f;
-        const uint32_t thr = drop_threshold(a.drop_p);
-        const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-        for (int k = 0; k < 64; ++k) {
-            float v = fmaxf(fmaf(sT[tid][k], sSc[k], sSh[k]), 0.f);
-            if (a.drop_p > 0.f) v = (mix32(((uint32_t)row * 64u + (uint32_t)k) ^ a.drop_seed) >= thr) ? v * dscale : 0.f;
-#pragma unroll
-            for (int c = 0; c < HEAD_MAX_CLASSES; ++c)
-                if (c < a.C) acc[c] = fmaf(v, sW[c][k], acc[c]);
-        }
+        for (int c = 0; c < HEAD_MAX_CLASSES; ++c) acc[c] = c < a.C ? z4[(size_t)row * ldz4 + c] : 0.f;
         const int b = row / a.P, p = row % a.P;
         float m = acc[0];
         int am = 0;
@@ -195,21 +160,21 @@ __global__ __launch_bounds__(HO_ROWS) void head_out_kernel(HeadOut a)
         }
         __syncthreads();
         if (tid == 0) {
-            a.loss_part[blockIdx.x * 2 + 0] = red[0][0] + red[1][0];
-            a.loss_part[blockIdx.x * 2 + 1] = red[0][1] + red[1][1];
+            a.loss_part[blockIdx.x * 2 + 0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            a.loss_part[blockIdx.x * 2 + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         }
     }
 }
 
-int head_out(const HeadOut &a, int *n_blocks, hipStream_t st)
+int head_logits(const HeadOut &a, const float *z4, int ldz4, int *n_blocks, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.z3 && a.scale && a.shift && a.W && a.bias && a.logits, "head_out: null pointer");
-    AMPNET_REQUIRE(a.C >= 1 && a.C <= HEAD_MAX_CLASSES, "head_out: %d classes, supported 1..%d", a.C, HEAD_MAX_CLASSES);
-    AMPNET_REQUIRE(a.P >= 1 && a.R % a.P == 0, "head_out: rows %d not a multiple of points per sample %d", a.R, a.P);
-    const int blocks = cdiv(a.R, HO_ROWS);
+    AMPNET_REQUIRE(z4 && a.logits && ldz4 >= a.C, "head_logits: null pointer / ldz4");
+    AMPNET_REQUIRE(a.C >= 1 && a.C <= HEAD_MAX_CLASSES, "head_logits: %d classes, supported 1..%d", a.C, HEAD_MAX_CLASSES);
+    AMPNET_REQUIRE(a.P >= 1 && a.R % a.P == 0, "head_logits: rows %d not a multiple of points per sample %d", a.R, a.P);
+    const int blocks = cdiv(a.R, HL_ROWS);
     if (n_blocks) *n_blocks = blocks;
-    hipLaunchKernelGGL(head_out_kernel, dim3(blocks), dim3(HO_ROWS), 0, st, a);
-    return check_launch("head_out_kernel");
+    hipLaunchKernelGGL(head_logits_kernel, dim3(blocks), dim3(HL_ROWS), 0, st, a, z4, ldz4);
+    return check_launch("head_logits_kernel");
 }
 
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float *__restrict__ part, int n, float *__restrict__ out)

@@ -30,6 +30,7 @@ struct HeadWs {
     float *part_sum, *part_sq;                     // [max(Q*chunks, tok_chunks), 128]
     float *merge;                                  // two-stage bn_finalize scratch
     float *loss_part;                              // [blocks, 2]
+    float *z4;                                     // [R, 8] conv_4 output (row-major, padded)
     BnSlot1 bn2, bn3;
     size_t bytes;
 };
@@ -57,7 +58,8 @@ struct HeadOut {
     long long *preds = nullptr;            // [B, P] int64 or nullptr
     float *loss_part = nullptr;            // [blocks, 2]: sum w * nll, sum w
 };
-int head_out(const HeadOut &a, int *n_blocks, hipStream_t st);
+// conv_4 runs as a pw_gemm (z4 [R, ldz4]); this is its tail: logits / preds / CE partials (HeadOut.z3, W, bias unused)
+int head_logits(const HeadOut &a, const float *z4, int ldz4, int *n_blocks, hipStream_t st);
 int loss_finalize(const float *loss_part, int n_blocks, float *loss_out, hipStream_t st);   // loss_out[0] = ce, [1] = sum w
 
 }  // namespace ampnet

@@ -8,7 +8,8 @@
 // epilogue of the 64 -> 128 per-point GEMM.  Launch sequence:
 //   posenc_tokens -> pw_gemm 256->768 (in_proj) -> attention_core -> pw_gemm 256->256 (out_proj)
 //   -> pw_gemm 256->128 (token half of conv_2) -> pw_gemm 64->128 (+per-window bias, bn_2 stats)
-//   -> pw_gemm 128->64 (bn_2+ReLU+dropout prologue, bn_3 stats) -> head_out (bn_3+ReLU+dropout, conv_4, CE, argmax)
+//   -> pw_gemm 128->64 (bn_2+ReLU+dropout prologue, bn_3 stats) -> pw_gemm 64->C (bn_3+ReLU+dropout prologue)
+//   -> head_logits (transposed store, CE, argmax)
 #include "head.h"
 
 namespace ampnet {
@@ -73,6 +74,7 @@ void head_carve(const HeadShape &s, void *base, HeadWs &ws)
     ws.part_sq = c.take<float>(np);
     ws.merge = c.take<float>(bn_finalize_merge_floats(1, 128));
     ws.loss_part = c.take<float>((size_t)cdiv(s.R, 128) * 2);
+    ws.z4 = c.take<float>(R * HEAD_MAX_CLASSES);
     carve_bn(c, ws.bn2, 128);
     carve_bn(c, ws.bn3, 64);
     ws.bytes = align_up(c.off, 256);
@@ -181,7 +183,16 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         o.logits = logits; o.targets = targets; o.class_w = class_w; o.preds = preds;
         o.loss_part = loss_out ? ws.loss_part : nullptr;
         int blocks = 0;
-        TRY(head_out(o, &blocks, st));
+        // conv_4 on the matrix cores (the 5 output columns ride in one 32-column MFMA tile), then the row-wise tail
+        PwGemm g;
+        g.A = ws.z3; g.lda = 64; g.cin = 64;
+        g.W = P[HP_CONV4_W]; g.ldw = 64; g.bias = P[HP_CONV4_B];
+        g.pro_scale = ws.bn3.scale; g.pro_shift = ws.bn3.shift;
+        g.drop_p = dp; g.drop_seed = drop_base(seed, 2);
+        g.Z = ws.z4; g.ldz = HEAD_MAX_CLASSES; g.cout = n_classes;
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
+        TRY(pw_gemm(g, st));
+        TRY(head_logits(o, ws.z4, HEAD_MAX_CLASSES, &blocks, st));
         if (loss_out) TRY(loss_finalize(ws.loss_part, blocks, loss_out, st));
     }
     if (tr) {

@@ -388,8 +388,8 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
         return fail(AMPNET_E_ARG, "pw_gemm: max-pool epilogue is built for cin 128, >64 columns, BatchNorm+ReLU prologue");
     }
     if (pro == 2) {
-        if constexpr (CIN == 128 && NT == 2) return launch_pw_x<CIN, NT, 2, false>(a, st);
-        return fail(AMPNET_E_ARG, "pw_gemm: dropout prologue is built for cin 128, 33..64 columns");
+        if constexpr ((CIN == 128 && NT == 2) || (CIN == 64 && NT == 1)) return launch_pw_x<CIN, NT, 2, false>(a, st);
+        return fail(AMPNET_E_ARG, "pw_gemm: dropout prologue is built for cin 128 / 33..64 columns and cin 64 / <= 32 columns");
     }
     return pro ? launch_pw_x<CIN, NT, 1, false>(a, st) : launch_pw_x<CIN, NT, 0, false>(a, st);
 }
