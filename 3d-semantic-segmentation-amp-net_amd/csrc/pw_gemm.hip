@@ -67,9 +67,15 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const int wave = tid >> 6;
     const int r = lane & 31;
     const int h = lane >> 5;
-    const int q = blockIdx.y;
-    const int chunk = blockIdx.x;
-    const int cb0 = blockIdx.z * CB;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so the column blocks of one
+    // block of rows get ids 8 apart -- same XCD, dispatched together: the second read of those rows hits that L2
+    const int ncb = (a.cout + CB - 1) / CB;
+    const int within = blockIdx.x % (8 * ncb);
+    const int rb = (blockIdx.x / (8 * ncb)) * 8 + within % 8;
+    if (rb >= a.Q * a.chunks) return;
+    const int q = rb / a.chunks;
+    const int chunk = rb % a.chunks;
+    const int cb0 = (within / 8) * CB;
 
     const int w_begin = a.win_off[q];
     const int w_end = a.win_off[q + 1];
@@ -360,7 +366,8 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
         }
         attr_set = true;
     }
-    dim3 grid(a.chunks, a.Q, cdiv(a.cout, CB));
+    const int n_rb = a.Q * a.chunks;
+    dim3 grid((unsigned)(cdiv(n_rb, 8) * 8 * cdiv(a.cout, CB)));
     char name[64];
     snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
     const double rows = (double)a.rows_hint;
