@@ -17,6 +17,7 @@
 //     order, both operands agree on it.
 //   * weights (<= 128 x 256 fp32 = 133 KB) are staged in LDS once per workgroup and reused for every row tile
 //     of the workgroup's chunk; A fragments are prefetched one 128-byte line per row ahead of the MFMAs.
+#include <type_traits>
 #include "kernels.h"
 
 namespace ampnet {
@@ -257,30 +258,36 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             }
             s_cnt += valid;
         }
+        // FULL: all 32 rows of the tile exist (every tile but a window's last): no row predicate at all
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = cb0 + 32 * t + r;
-            const bool cok = col < a.cout;
-            float *zp = a.Z + (size_t)row0 * a.ldz + col;
+            for (int t = 0; t < NT; ++t) {
+                const int col = cb0 + 32 * t + r;
+                const bool cok = col < a.cout;
+                float *zp = a.Z + (size_t)row0 * a.ldz + col;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float v = acc[t][e] + bias_v[t];
-                const bool ok = rr < valid;
-                if (do_store && ok && cok) zp[(size_t)rr * a.ldz] = v;
-                if (do_stats) {
-                    const float d = ok ? v - s_z0[t] : 0.f;
-                    s_sum[t] += d;
-                    s_sq[t] = fmaf(d, d, s_sq[t]);
-                }
-                if (POOL) {
-                    const float vs = ok ? v * sgn[t] : -__builtin_inff();
-                    const bool gt = vs > s_ext[t];               // strict: rows ascend, the first extreme wins
-                    s_ext[t] = gt ? vs : s_ext[t];
-                    s_arg[t] = gt ? row0 + rr : s_arg[t];
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[t][e] + bias_v[t];
+                    const bool ok = FULL || rr < valid;
+                    if (do_store && ok && cok) zp[(size_t)rr * a.ldz] = v;
+                    if (do_stats) {
+                        const float d = ok ? v - s_z0[t] : 0.f;
+                        s_sum[t] += d;
+                        s_sq[t] = fmaf(d, d, s_sq[t]);
+                    }
+                    if (POOL) {
+                        const float vs = ok ? v * sgn[t] : -__builtin_inff();
+                        const bool gt = vs > s_ext[t];               // strict: rows ascend, the first extreme wins
+                        s_ext[t] = gt ? vs : s_ext[t];
+                        s_arg[t] = gt ? row0 + rr : s_arg[t];
+                    }
                 }
             }
-        }
+        };
+        if (valid == 32) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
 
     if (!do_stats && !POOL) return;
