@@ -94,6 +94,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 const int j = e / (CIN / 4), k4 = e % (CIN / 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cb0 + j < a.cout) v = *reinterpret_cast<const f32x4 *>(Wg + (size_t)(cb0 + j) * a.ldw + 4 * k4);
+                if (POOL && a.pool_gamma && cb0 + j < a.cout && a.pool_gamma[cb0 + j] < 0.f) v = -v;     // z' = sgn(gamma) z: the pool tracks max z'
                 if (BF) {
                     bf16x4 b;
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
         sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
-        bias_v[t] = (a.bias && col < a.cout) ? a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
+        bias_v[t] = (a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the constants above have landed (see pw_bwd_fused.hip)
 
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                         s_sq[t] = fmaf(d, d, s_sq[t]);
                     }
                     if (POOL) {
-                        const float vs = ok ? v * sgn[t] : -__builtin_inff();
+                        const float vs = ok ? v : -__builtin_inff();          // v is already sgn(gamma) * z (signed weights)
                         const bool gt = vs > s_ext[t];               // strict: rows ascend, the first extreme wins
                         s_ext[t] = gt ? vs : s_ext[t];
                         s_arg[t] = gt ? row0 + rr : s_arg[t];
@@ -345,12 +346,12 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             }
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
+        const float sg = (POOL && a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
         if (do_stats) {
-            a.part_sum[o] = (float)mean;            // chunk mean
+            a.part_sum[o] = sg * (float)mean;       // chunk mean (of z, not of the signed z')
             a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
         if (POOL) {
-            const float sg = (a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
             a.part_max[o] = ext * sg;               // the extreme itself (max for gamma >= 0, min otherwise)
             a.part_amax[o] = arg;
         }
