@@ -526,6 +526,18 @@ __global__ void axpy_kernel(const float *__restrict__ x, float alpha, size_t n, 
     if (i < n) y[i] = fmaf(alpha, x[i], y[i]);
 }
 
+__global__ void fill_kernel(float *__restrict__ p, size_t n, float v)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int fill_f32(float *p, size_t n, float v, hipStream_t st)
+{
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+    return check_launch("fill_kernel");
+}
+
 int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
 {
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, alpha, n, y);
@@ -538,23 +550,27 @@ int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
 
 namespace ampnet {
 // dst[p(q)] = src[q]^T with p(q) the slot-major row of window q
-__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots, int chunks)
+__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots, int chunks, int by_workgroup)
 {
     __shared__ float t[64][65];
     const int q = blockIdx.x;
     const size_t p = (size_t)(q % n_slots) * (Q / n_slots) + q / n_slots;
     for (int e = threadIdx.x; e < 4096; e += 256) {
         float s = 0.f;
-        for (int ch = 0; ch < chunks; ++ch) s += src[((size_t)q * chunks + ch) * 4096 + e];     // the window's chunk partials, in order
+        for (int ch = 0; ch < chunks; ++ch) {              // the window's partials, in order
+            // by_workgroup: partials indexed like pw_bwd_fused's workgroups, ((q / n_slots) * chunks + ch) * n_slots + q % n_slots
+            const size_t pi = by_workgroup ? ((size_t)(q / n_slots) * chunks + ch) * n_slots + q % n_slots : (size_t)q * chunks + ch;
+            s += src[pi * 4096 + e];
+        }
         t[e / 64][e % 64] = s;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 4096; e += 256) dst[p * 4096 + e] = t[e % 64][e / 64];
 }
 
-int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, hipStream_t st)
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, int by_workgroup, hipStream_t st)
 {
-    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots, chunks);
+    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots, chunks, by_workgroup);
     return check_launch("transpose64_kernel");
 }
 }  // namespace ampnet

@@ -26,6 +26,7 @@ struct EncBwdWs {
     float *dWeff, *dT3;        // [Q, 576], [Q, 12]
     float *srows, *Gm, *c0, *gram, *asum;   // [Q*256,128] [S,128,128] [S,128] [S,128,128] [S,128]: pooled-layer algebra
     int *srow_row, *srow_cnt;  // [Q*256], [Q]
+    float *ones64, *zeros64;   // [n_slots, 64] identity BatchNorm-backward constants (g = dy) for the fused bmm backward
     BnBwdSlot bn[BN_ENC_COUNT];
     size_t bytes;
 };
@@ -78,6 +79,8 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.asum = c.take<float>((size_t)s.n_slots * 128);
     w.srow_row = c.take<int>(Q * 256);
     w.srow_cnt = c.take<int>(Q);
+    w.ones64 = c.take<float>((size_t)s.n_slots * 64);
+    w.zeros64 = c.take<float>((size_t)s.n_slots * 64);
     for (int i = 0; i < BN_ENC_COUNT; ++i) {
         const size_t n = (size_t)s.n_slots * kBnC2[i];
         w.bn[i].P1 = c.take<float>(n);
@@ -374,22 +377,55 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     // ---- local = h x T64[window]: dT64 (per window, no reduction) and d_h ---------------------------------
     {
-        PwWgrad w;                                   // dT^T[j][k] = sum_rows d_local[row][j] * h[row][k]
-        w.x = e.dense(b.d_local, nullptr, -1, 64);
-        w.y = e.act(f.z_c2, BN_C2, 64);
-        w.dWpart = b.dT64t; w.ldp = 64;
-        w.win_off = win_off; w.Q = Q; w.n_slots = n_slots; w.rows_hint = total_rows;
-        w.chunk_rows = e.s.chunk_rows; w.chunks = e.s.chunks;      // several workgroups per window: no half-empty last round
-        TRY(pw_wgrad(w, st));
-        // window q's matrix (sum of its chunk partials) belongs at the slot-major row the forward used for feat_T
-        TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, e.s.chunks, st));
-        if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
-        PwDgrad d;                                   // d_h[row][k] = sum_j d_local[row][j] * T[k][j]
-        d.g = e.dense(b.d_local, nullptr, -1, 64);
-        d.W = feat_T; d.w_win_stride = 4096; d.perwin_slot_major = 1;
-        d.out = b.d_h; d.cp = 64;
-        d.win_off = win_off; d.Q = Q; d.n_slots = n_slots; d.chunk_rows = e.s.chunk_rows; d.chunks = e.s.chunks; d.rows_hint = total_rows;
-        TRY(pw_dgrad(d, st));
+        // items (256-row chunks) per workgroup: a divisor of the chunks per window (a workgroup stays inside one window), at most
+        // s.chunks partials per window (buffer size), and the fullest last round of 256 workgroups
+        const int cpw = cdiv(max_rows, pw_bwd_item_rows());
+        int ipb = 0;
+        double best = -1.0;
+        for (int d = 1; d <= cpw && d <= 8; ++d) {
+            if (cpw % d || cpw / d > e.s.chunks) continue;
+            const long blocks = (long)Q * (cpw / d);
+            const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+            if (eff >= best) {
+                best = eff;
+                ipb = d;
+            }
+        }
+        const int bpw = ipb ? cpw / ipb : 0;                        // workgroups per window
+        if (e.fused && ipb > 0) {
+            // one pass over (d_local, z_c2): dT^T[j][k] = sum_rows d_local[row][j] h[row][k] per window AND
+            // d_h[row][k] = sum_j d_local[row][j] T[k][j] (masked by conv_2's ReLU here already: the mask is idempotent and the
+            // feature T-Net's conv_1 backward applies it again after adding its own term).  g = dy via identity constants.
+            TRY(fill_f32(b.ones64, (size_t)n_slots * 64, 1.0f, st));
+            TRY(fill_f32(b.zeros64, (size_t)n_slots * 64, 0.0f, st));
+            PwBwd p;
+            p.g.dy = b.d_local; p.g.z = b.d_local; p.g.C = 64; p.g.P1 = b.ones64; p.g.P2 = b.zeros64; p.g.P3 = b.zeros64;
+            p.prev = e.act(f.z_c2, BN_C2, 64);
+            p.W = feat_T; p.ldw = 64; p.w_win_stride = 4096; p.perwin_slot_major = 1;
+            p.out = b.d_h; p.dWpart = b.dT64t;
+            p.win_off = win_off; p.Q = Q; p.n_slots = n_slots; p.max_rows = max_rows; p.rows_hint = total_rows;
+            p.items_per_block = ipb; p.blocks_per_slot = (Q / n_slots) * bpw;
+            TRY(pw_bwd_fused(p, st));
+            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, bpw, 1, st));
+            if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
+        } else {
+            PwWgrad w;                                   // dT^T[j][k] = sum_rows d_local[row][j] * h[row][k]
+            w.x = e.dense(b.d_local, nullptr, -1, 64);
+            w.y = e.act(f.z_c2, BN_C2, 64);
+            w.dWpart = b.dT64t; w.ldp = 64;
+            w.win_off = win_off; w.Q = Q; w.n_slots = n_slots; w.rows_hint = total_rows;
+            w.chunk_rows = e.s.chunk_rows; w.chunks = e.s.chunks;      // several workgroups per window: no half-empty last round
+            TRY(pw_wgrad(w, st));
+            // window q's matrix (sum of its chunk partials) belongs at the slot-major row the forward used for feat_T
+            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, e.s.chunks, 0, st));
+            if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
+            PwDgrad d;                                   // d_h[row][k] = sum_j d_local[row][j] * T[k][j]
+            d.g = e.dense(b.d_local, nullptr, -1, 64);
+            d.W = feat_T; d.w_win_stride = 4096; d.perwin_slot_major = 1;
+            d.out = b.d_h; d.cp = 64;
+            d.win_off = win_off; d.Q = Q; d.n_slots = n_slots; d.chunk_rows = e.s.chunk_rows; d.chunks = e.s.chunks; d.rows_hint = total_rows;
+            TRY(pw_dgrad(d, st));
+        }
     }
     // ---- feature T-Net ---------------------------------------------------------------------------------------
     TRY(e.tnet_fc_bwd(EP_FT, BN_F1, b.dT64, 4096, f.pool_f, f.z_ff1, f.z_ff2));

@@ -217,6 +217,8 @@ struct PwBwd {
     const float *W = nullptr;      // [CX][ldw] torch layout (row = output channel of layer l, column = input channel)
     int ldw = 0;
     long w_slot_stride = 0;        // != 0: per-slot weights at W + slot * w_slot_stride
+    long w_win_stride = 0;         // != 0: per-window matrix T[pidx(q)][CY][CX] (the bmm transform); needs items_per_block
+    int perwin_slot_major = 0;     // pidx(q) = (q % n_slots) * (Q / n_slots) + q / n_slots instead of q
     const float *bias_slot = nullptr;   // [n_slots, CY] added to every dgrad row of the slot
     const float *add = nullptr;    // [rows, CY] added to the dgrad output
     float *out = nullptr;          // [rows, CY] dy_{l-1} (masked)

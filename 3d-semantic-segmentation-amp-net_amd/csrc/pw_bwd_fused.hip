@@ -56,7 +56,17 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
 
     // ---- stage the transposed weight and load the per-thread constants ----
-    {
+    if (a.w_win_stride != 0) {
+        // per-window matrix T[pidx][cy][cx] (the bmm transform, already "transposed": out[row][cy] = sum_cx g[row][cx] T[cy][cx]);
+        // the host keeps every workgroup inside one window (items_per_block divides the chunks per window)
+        const int bi = item_begin / cpw;
+        const int pidx = a.perwin_slot_major ? slot * (a.Q / a.n_slots) + bi : bi * a.n_slots + slot;
+        const float *Tq = a.W + (size_t)pidx * a.w_win_stride;
+        for (int e = tid; e < CY * (CX / 4); e += FB_THREADS) {
+            const int j = e / (CX / 4), k4 = e % (CX / 4);
+            *reinterpret_cast<f32x4 *>(sWt + j * LDG + 4 * k4) = *reinterpret_cast<const f32x4 *>(Tq + (size_t)j * CX + 4 * k4);
+        }
+    } else {
         const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
         for (int e = tid; e < CX * (CY / 4); e += FB_THREADS) {
             const int k = e % CX, j4 = e / CX;
@@ -467,6 +477,8 @@ int pw_bwd_fused(const PwBwd &a, hipStream_t st)
     AMPNET_REQUIRE(a.g.act ? a.g.z == a.prev.z : (a.g.dy && a.g.P1), "pw_bwd_fused: dense gradient with BatchNorm constants, or the Gram form of one tensor");
     AMPNET_REQUIRE(a.g.P2 && a.g.P3 && a.g.z, "pw_bwd_fused: BatchNorm constants incomplete");
     AMPNET_REQUIRE(!a.part_a || (a.part_b && a.prev.s), "pw_bwd_fused: partial sums need the previous layer's BatchNorm");
+    AMPNET_REQUIRE(a.w_win_stride == 0 || (a.items_per_block > 0 && ((a.max_rows + FB_ITEM_ROWS - 1) / FB_ITEM_ROWS) % a.items_per_block == 0 && a.Q % a.n_slots == 0),
+                   "pw_bwd_fused: per-window weights need workgroups that stay inside one window");
     AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
     AMPNET_REQUIRE(a.prev.C == 0 || pw_bwd_supported(a.g.C, a.prev.C), "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
     if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);
