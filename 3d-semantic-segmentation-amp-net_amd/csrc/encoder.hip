@@ -11,7 +11,8 @@
 //   pw_gemm 64->64 with per-window weights T64 (the torch.bmm)                                           local features
 //   pw_gemm 64->64 -> 64->128 -> 128->128 -> 128->256 + maxpool                                          conv_3..6, global
 // Every layer stores its PRE-BatchNorm output; BatchNorm + ReLU are applied by the consumer's prologue, the
-// 256-channel pooled layers are never materialised in eval mode (only their per-window max/min).
+// 256-channel pooled layers are never materialised in either mode (only one signed extreme per window chunk and channel,
+// its row and its value: the backward of those layers is algebraic, encoder_bwd.hip).
 #include "encoder.h"
 
 namespace ampnet {

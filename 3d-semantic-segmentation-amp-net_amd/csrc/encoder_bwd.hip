@@ -2,7 +2,8 @@
 // of a step (the reference: loss.backward() at train_pointnet-attention.py:467 through pointnetAtt.py:80-112).
 //
 // Walks the forward launch sequence of encoder.hip in reverse.  Per BatchNorm'ed layer l (reverse order):
-//     [pool_bwd | bn_bwd_finalize]  ->  pw_wgrad(l) + reduce_windows  ->  pw_dgrad(l)  -> next layer's finalize
+//     [pool_bwd | bn_bwd_finalize]  ->  pw_bwd_fused(l): weight gradient partials + dy_{l-1} in one pass  ->  reduce_windows
+//     -> next layer's finalize            (AMPNET_FUSED_BWD=0: the separate pw_wgrad / pw_dgrad launches of pw_bwd.hip)
 // using only what the train-mode forward left in its workspace (pre-BatchNorm z, batch mean / invstd / affine,
 // argmax rows) plus two ping-pong dy buffers.  Train mode only (batch statistics).
 #include <cstdlib>
