@@ -62,33 +62,28 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     float *sW = smem;                  // fp32: [CB][LDW]
     __bf16 *sWb = reinterpret_cast<__bf16 *>(smem);   // bf16: [CB][LDB]
     float *sPro = BF ? smem + CB * LDB / 2 : smem + CB * LDW;     // scale[CIN], shift[CIN]
+    float *sRed = sPro + 2 * CIN;                                  // cross-wave reduction scratch (the weights stay resident)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31;
     const int h = lane >> 5;
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so the column blocks of one
-    // block of rows get ids 8 apart -- same XCD, dispatched together: the second read of those rows hits that L2
+    // Persistent workgroups: workgroup (lane, column block) walks the blocks of rows rb = lane, lane + G, ... with the SAME weight
+    // tile resident in LDS (staged once, not once per 512 rows).  XCD-aware order: workgroups are dealt round-robin to the
+    // 8 XCDs (own L2 each), so the column blocks of one lane get ids 8 apart -- same XCD, same rows at the same time: the
+    // second read of those rows hits that L2.
     const int ncb = (a.cout + CB - 1) / CB;
     const int within = blockIdx.x % (8 * ncb);
-    const int rb = (blockIdx.x / (8 * ncb)) * 8 + within % 8;
-    if (rb >= a.Q * a.chunks) return;
-    const int q = rb / a.chunks;
-    const int chunk = rb % a.chunks;
+    const int lane_id = (blockIdx.x / (8 * ncb)) * 8 + within % 8;
+    const int n_lanes = (gridDim.x / (8 * ncb)) * 8;
+    const int n_rb = a.Q * a.chunks;
     const int cb0 = (within / 8) * CB;
+    const bool perwin_w = a.w_win_stride != 0;
 
-    const int w_begin = a.win_off[q];
-    const int w_end = a.win_off[q + 1];
-    const int row_begin = w_begin + chunk * a.chunk_rows;
-    const int row_end = min(w_end, row_begin + a.chunk_rows);
-    const int nrows = max(row_end - row_begin, 0);
-    const int slot = (a.n_slots > 1) ? (q % a.n_slots) : 0;
-    const int pidx = pidx_of(q, a.n_slots, a.Q, a.perwin_slot_major);
-
-    // ---- stage weights (transposing when they are k-major) and the prologue affine ----
-    if (nrows > 0) {
-        if (a.w_win_stride == 0) {
+    // ---- weight staging (transposing when the matrix is k-major) ----
+    auto stage_weights = [&](int pidx) {
+        if (!perwin_w) {
             const float *Wg = a.W;
             for (int e = tid; e < CB * (CIN / 4); e += PW_NW * 64) {
                 const int j = e / (CIN / 4), k4 = e % (CIN / 4);
@@ -113,14 +108,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 else sW[j * LDW + k] = v;
             }
         }
-        if (PRO) {
-            for (int e = tid; e < CIN; e += PW_NW * 64) {
-                sPro[e] = a.pro_scale[(size_t)slot * CIN + e];
-                sPro[CIN + e] = a.pro_shift[(size_t)slot * CIN + e];
-            }
-        }
-    }
-    __syncthreads();
+    };
+    if (!perwin_w) stage_weights(0);
 
     const uint32_t dthr = drop_threshold(a.drop_p);
     const uint32_t dbase = a.drop_seed;
@@ -128,12 +117,45 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const bool do_stats = a.part_sum != nullptr;
     const bool do_store = a.Z != nullptr;
 
+    float sgn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = cb0 + 32 * t + r;
+        sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
+    }
+    int staged_slot = -1;
+  for (int rb = lane_id; rb < n_rb; rb += n_lanes) {
+    const int q = rb / a.chunks;
+    const int chunk = rb % a.chunks;
+    const int w_begin = a.win_off[q];
+    const int w_end = a.win_off[q + 1];
+    const int row_begin = w_begin + chunk * a.chunk_rows;
+    const int row_end = min(w_end, row_begin + a.chunk_rows);
+    const int nrows = max(row_end - row_begin, 0);
+    const int slot = (a.n_slots > 1) ? (q % a.n_slots) : 0;
+    const int pidx = pidx_of(q, a.n_slots, a.Q, a.perwin_slot_major);
+
+    // everything the previous block of rows read from LDS (prologue constants, per-window weights, reduction scratch) is done
+    __syncthreads();
+    const bool restage = perwin_w || (PRO && slot != staged_slot);
+    if (restage) {
+        if (perwin_w) stage_weights(pidx);
+        if (PRO) {
+            for (int e = tid; e < CIN; e += PW_NW * 64) {
+                sPro[e] = a.pro_scale[(size_t)slot * CIN + e];
+                sPro[CIN + e] = a.pro_shift[(size_t)slot * CIN + e];
+            }
+        }
+        staged_slot = slot;
+        __syncthreads();
+    }
+
     // BatchNorm statistics are accumulated as sums of (v - z0) and (v - z0)^2 with z0 = the wave's first
     // row: E[z^2] - mean^2 in fp32 loses everything when a channel's spread is small against its mean
     // (the T-Net FC layers normalise over only B rows of near-identical pooled features).
     // MaxPool: BatchNorm + ReLU are monotone per channel with the direction of sign(gamma) (scale = gamma * invstd), so one
-    // signed extreme per channel is enough: ext = max over rows of sgn * v.
-    float s_sum[NT], s_sq[NT], s_ext[NT], s_z0[NT], sgn[NT], bias_v[NT];
+    // signed extreme per channel is enough: ext = max over rows of sgn * v (the sign is folded into the staged weights).
+    float s_sum[NT], s_sq[NT], s_ext[NT], s_z0[NT], bias_v[NT];
     int s_arg[NT];
     int s_cnt = 0;
 #pragma unroll
@@ -144,10 +166,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         s_sq[t] = 0.f;
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
-        sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
         bias_v[t] = (a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the constants above have landed (see pw_bwd_fused.hip)
 
     const int ntiles = (nrows + 31) / 32;
     // A fragments: blocks of 4 j (= 32 k = one 128-byte line per row), the next block prefetched in registers
@@ -291,12 +311,11 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         else epilogue(std::false_type{});
     }
 
-    if (!do_stats && !POOL) return;
+    if (!do_stats && !POOL) continue;
 
-    // ---- combine the two half-waves, then the waves (LDS scratch reuses the weight tile) ----
-    __syncthreads();
-    float *red_f = smem;                                           // [PW_NW][CB][4]: S1, S2, ext, z0
-    int *red_i = reinterpret_cast<int *>(smem + PW_NW * CB * 4);   // [PW_NW][CB]: arg
+    // ---- combine the two half-waves, then the waves ----
+    float *red_f = sRed;                                           // [PW_NW][CB][4]: S1, S2, ext, z0
+    int *red_i = reinterpret_cast<int *>(sRed + PW_NW * CB * 4);   // [PW_NW][CB]: arg
     int *red_n = red_i + PW_NW * CB;                               // [PW_NW] rows seen by the wave
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             a.part_amax[o] = arg;
         }
     }
+  }   // blocks of rows
 }
 
 template <int CIN, int NT, int PRO, bool POOL, bool BF>
@@ -364,18 +384,25 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = BF ? (size_t)CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
     constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
-    constexpr size_t lds = lds_main > lds_red ? lds_main : lds_red;
-    static bool attr_set = false;
+    constexpr size_t lds = lds_main + lds_red;
+    static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
     auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF>;
-    if (!attr_set) {
+    if (resident == 0) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_gemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         }
-        attr_set = true;
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), PW_NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = per_cu * cus;
     }
-    const int n_rb = a.Q * a.chunks;
-    dim3 grid((unsigned)(cdiv(n_rb, 8) * 8 * cdiv(a.cout, CB)));
+    // persistent grid: as many workgroups as fit at once, in units of (8 XCDs x column blocks); never more lanes than blocks of rows
+    const int n_rb = a.Q * a.chunks, ncb = cdiv(a.cout, CB);
+    int lanes = (resident / (8 * ncb)) * 8;
+    if (lanes < 8) lanes = 8;
+    if (lanes > cdiv(n_rb, 8) * 8) lanes = cdiv(n_rb, 8) * 8;
+    dim3 grid((unsigned)(lanes * ncb));
     char name[64];
     snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
     const double rows = (double)a.rows_hint;
