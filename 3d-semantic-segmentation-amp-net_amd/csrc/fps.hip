@@ -33,7 +33,7 @@ __device__ __forceinline__ void dpp_max64(uint32_t &hi, uint32_t &lo)
 {
     const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
     const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
-    const bool take = (ohi > hi) || (ohi == hi && olo > lo);
+    const bool take = (((unsigned long long)ohi << 32) | olo) > (((unsigned long long)hi << 32) | lo);      // one v_cmp_gt_u64
     hi = take ? ohi : hi;
     lo = take ? olo : lo;
 }
@@ -49,7 +49,7 @@ __device__ __forceinline__ void row16_max64(uint32_t &hi, uint32_t &lo)
 
 __device__ __forceinline__ void smax64(uint32_t &hi, uint32_t &lo, uint32_t ohi, uint32_t olo)
 {
-    const bool take = (ohi > hi) || (ohi == hi && olo > lo);
+    const bool take = (((unsigned long long)ohi << 32) | olo) > (((unsigned long long)hi << 32) | lo);
     hi = take ? ohi : hi;
     lo = take ? olo : lo;
 }
@@ -213,8 +213,9 @@ extern "C" int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int
     if (n <= 256) return launch<256, 1>(xyz, n_clouds, n, ld, s, idx, st);
     if (n <= 1024) return launch<256, 4>(xyz, n_clouds, n, ld, s, idx, st);
     if (n <= 2048) return launch<512, 4>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 4096) return launch<1024, 4>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 8192) return launch<1024, 8>(xyz, n_clouds, n, ld, s, idx, st);
+    // 16 points per thread from 4096 points on: a round is bound by the argmax reduction, and half the waves halve it
+    if (n <= 4096) return launch<512, 8>(xyz, n_clouds, n, ld, s, idx, st);
+    if (n <= 8192) return launch<512, 16>(xyz, n_clouds, n, ld, s, idx, st);
     return launch<1024, 16>(xyz, n_clouds, n, ld, s, idx, st);
 }
 

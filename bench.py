@@ -208,7 +208,7 @@ def bench_fps(args, dev, rank, world, dist):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"farthest-point sampling, {B} clouds x {N} points -> {S} samples per GPU", "parallelism": f"replicas{world}"},
-               "roofline": {"bound": "hbm", "kernel": "fps_kernel<1024,8>", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+               "roofline": {"bound": "hbm", "kernel": "fps_kernel<512,16>", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "launch_ms": round(kern_ms, 4),
                             "note": "algorithmic 16 B per (candidate, round); the cloud is register-resident, true HBM traffic is B*(N*12+S*4) bytes"}}
         knn_bytes = float(B) * S * N * 12
