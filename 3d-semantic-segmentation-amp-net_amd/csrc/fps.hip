@@ -54,6 +54,19 @@ __device__ __forceinline__ void smax64(uint32_t &hi, uint32_t &lo, uint32_t ohi,
     lo = take ? olo : lo;
 }
 
+// max over groups of 8 / 4 consecutive lanes (the slot fold of workgroups with <= 8 / <= 4 waves: fewer dependent steps)
+__device__ __forceinline__ void row8_max64(uint32_t &hi, uint32_t &lo)
+{
+    dpp_max64<0xB1>(hi, lo);
+    dpp_max64<0x4E>(hi, lo);
+    dpp_max64<0x141>(hi, lo);    // row_half_mirror: lane l <-> 7 - l inside each half row
+}
+__device__ __forceinline__ void row4_max64(uint32_t &hi, uint32_t &lo)
+{
+    dpp_max64<0xB1>(hi, lo);
+    dpp_max64<0x4E>(hi, lo);
+}
+
 // LXYZ: a copy of the cloud's coordinates lives in LDS (n * 12 bytes <= 144 KB), so a round only carries (distance,
 // index) through the reductions and reads the winner's coordinates with three broadcast LDS loads; otherwise the
 // coordinates travel with the per-thread / per-wave winner.
@@ -145,9 +158,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
         }
         __syncthreads();
         // ---- fold the wave slots: lane l of every row reads slot l & 15, one row-of-16 DPP max, every lane has it ----
-        const uint32_t mhi = s_hi[g][lane & 15], mlo = s_lo[g][lane & 15];
+        constexpr int FOLD = NW <= 4 ? 4 : (NW <= 8 ? 8 : 16);          // slots replicated every FOLD lanes
+        const uint32_t mhi = s_hi[g][lane & (FOLD - 1)], mlo = s_lo[g][lane & (FOLD - 1)];
         uint32_t fhi = mhi, flo = mlo;
-        row16_max64(fhi, flo);
+        if (FOLD == 4) row4_max64(fhi, flo);
+        else if (FOLD == 8) row8_max64(fhi, flo);
+        else row16_max64(fhi, flo);
         const int gi = (int)~flo;
         if (LXYZ) {
             lx = s_cloud[gi];
