@@ -192,13 +192,19 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 // fetched into registers while the current one is multiplied.  The problems are tiny (M or N = a few hundred
 // rows): small tiles keep every CU busy, which matters more than per-block efficiency.
 // ----------------------------------------------------------------------------------------------------
+// Split-K inside the workgroup: the problems are latency-bound (K of a few hundred, a few dozen workgroups), so SK = 4 groups
+// of 256 threads each walk a quarter of K with their own LDS tiles and the partial 32 x 32 tiles are summed through LDS in a
+// fixed order -- a quarter of the dependent (load -> barrier -> multiply) trips per launch.
+constexpr int SG_SK = 4;
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void sgemm_small_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
-                                                         const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int accumulate)
+__global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                                 const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int accumulate)
 {
-    __shared__ float sA[32][33], sB[32][33];     // [k][m], [k][n]
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    __shared__ float sA[SG_SK][32][33], sB[SG_SK][32][33];     // [group][k][m], [group][k][n]
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    // group g owns the k tiles g, g + SK, ... (32 deep each)
     float acc[2][2] = {};
     float ra[4], rb[4];
     auto fetch = [&](int k0) {
@@ -219,25 +225,39 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(int M, int N, int K, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
-            if (TA) sA[e / 32][e % 32] = ra[i]; else sA[e % 32][e / 32] = ra[i];
-            if (TB) sB[e % 32][e / 32] = rb[i]; else sB[e / 32][e % 32] = rb[i];
+            if (TA) sA[grp][e / 32][e % 32] = ra[i]; else sA[grp][e % 32][e / 32] = ra[i];
+            if (TB) sB[grp][e % 32][e / 32] = rb[i]; else sB[grp][e / 32][e % 32] = rb[i];
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    const int ktiles = (K + 31) / 32;
+    const int trips = (ktiles + SG_SK - 1) / SG_SK;            // the same for every group (the barriers are workgroup-wide)
+    fetch(32 * grp);
+    for (int i = 0; i < trips; ++i) {
+        const int kt = grp + i * SG_SK;
         __syncthreads();
         stash();
         __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
+        if (i + 1 < trips) fetch(32 * (kt + SG_SK));           // tiles past K load zeros
+        if (kt < ktiles) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float a0 = sA[k][ty], a1 = sA[k][ty + 16], b0 = sB[k][tx], b1 = sB[k][tx + 16];
-            acc[0][0] = fmaf(a0, b0, acc[0][0]);
-            acc[0][1] = fmaf(a0, b1, acc[0][1]);
-            acc[1][0] = fmaf(a1, b0, acc[1][0]);
-            acc[1][1] = fmaf(a1, b1, acc[1][1]);
+            for (int k = 0; k < 32; ++k) {
+                const float a0 = sA[grp][k][ty], a1 = sA[grp][k][ty + 16], b0 = sB[grp][k][tx], b1 = sB[grp][k][tx + 16];
+                acc[0][0] = fmaf(a0, b0, acc[0][0]);
+                acc[0][1] = fmaf(a0, b1, acc[0][1]);
+                acc[1][0] = fmaf(a1, b0, acc[1][0]);
+                acc[1][1] = fmaf(a1, b1, acc[1][1]);
+            }
         }
     }
+    // sum the SK partial tiles in group order
+    __syncthreads();
+    float *red = &sA[0][0][0];                                  // [SK][4][256]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) red[(grp * 4 + i * 2 + j) * 256 + tid] = acc[i][j];
+    __syncthreads();
+    if (grp != 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int gm = m0 + ty + 16 * i;
@@ -245,8 +265,11 @@ __global__ __launch_bounds__(256) void sgemm_small_kernel(int M, int N, int K, c
         for (int j = 0; j < 2; ++j) {
             const int gn = n0 + tx + 16 * j;
             if (gm < M && gn < N) {
+                float v = 0.f;
+#pragma unroll
+                for (int g2 = 0; g2 < SG_SK; ++g2) v += red[(g2 * 4 + i * 2 + j) * 256 + tid];
                 float *d = C + (size_t)gm * ldc + gn;
-                *d = accumulate ? *d + acc[i][j] : acc[i][j];
+                *d = accumulate ? *d + v : v;
             }
         }
     }
@@ -260,10 +283,10 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
     char name[64];
     snprintf(name, sizeof(name), "sgemm_small");
     ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), st);
-    if (transA && transB) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else if (transA) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else if (transB) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    if (transA && transB) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else if (transA) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else if (transB) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
+    else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
     return check_launch("sgemm_small_kernel");
 }
 
