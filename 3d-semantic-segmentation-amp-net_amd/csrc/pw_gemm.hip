@@ -444,7 +444,10 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_gemm: part_sum/part_sq must come together");
     AMPNET_REQUIRE(!a.part_max || a.part_amax, "pw_gemm: pool partials incomplete");
-    const int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);
+    int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);
+    // tiny problems (the T-Net FC layers: nine blocks of 64 rows): narrower column blocks = more workgroups, each staging a
+    // smaller weight tile -- they are bound by that staging latency, not by the matrix cores
+    while (nt > 1 && !a.part_max && !(a.drop_p > 0.f) && (long)a.Q * a.chunks * cdiv(a.cout, 32 * nt) < 128) nt >>= 1;
     switch (a.cin) {
     case 64:
         if (nt == 4) return launch_pw<64, 4>(a, st);
