@@ -480,19 +480,19 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
                                                                const float *__restrict__ T, int Q, int n_slots, int slot_major, int mode,
                                                                float *__restrict__ dW, float *__restrict__ dT)
 {
-    if (blockIdx.x == 0) {
-        // block 0: the weight gradient, thread = (channel c, window group g); groups summed in fixed order
-        __shared__ float red[4][64][12];
-        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (blockIdx.x < 4) {
+        // blocks 0..3: the weight gradient of 16 channels each, thread = (channel c, window group g of 16); groups summed in fixed order
+        __shared__ float red[16][16][12];
+        const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
         float s[12];
 #pragma unroll
         for (int f = 0; f < 12; ++f) s[f] = 0.f;
         // four windows per trip: their loads (9 gradient values, 9 transform entries each) are issued before the first use
-        for (int q0 = g; q0 < Q; q0 += 16) {
+        for (int q0 = g; q0 < Q; q0 += 64) {
             float ev[4][9], tv[4][9];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int q = q0 + 4 * u;
+                const int q = q0 + 16 * u;
                 const bool live = q < Q;
                 const float *e = dWeff + ((size_t)(live ? q : 0) * 64 + c) * 9;
                 const int p = slot_major ? ((live ? q : 0) % n_slots) * (Q / n_slots) + (live ? q : 0) / n_slots : (live ? q : 0);
@@ -516,15 +516,20 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
             }
         }
 #pragma unroll
-        for (int f = 0; f < 12; ++f) red[g][c][f] = s[f];
+        for (int f = 0; f < 12; ++f) red[g][cl][f] = s[f];
         __syncthreads();
         if (g == 0) {
             const int nf = mode == 0 ? 3 : 12;
-            for (int f = 0; f < nf; ++f) dW[c * nf + f] = (red[0][c][f] + red[1][c][f]) + (red[2][c][f] + red[3][c][f]);
+            for (int f = 0; f < nf; ++f) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v += red[k][cl][f];
+                dW[c * nf + f] = v;
+            }
         }
     } else if (mode == 1) {
-        // blocks 1..: dT for windows, one (q, i, d) per thread
-        const int idx = (blockIdx.x - 1) * 256 + threadIdx.x;
+        // blocks 4..: dT for windows, one (q, i, d) per thread
+        const int idx = (blockIdx.x - 4) * 256 + threadIdx.x;
         if (idx >= Q * 9) return;
         const int q = idx / 9, i = (idx % 9) / 3, d = idx % 3;
         const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
 int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
                       float *dT, hipStream_t st)
 {
-    const int blocks = 1 + (mode == 1 ? cdiv(Q * 9, 256) : 0);
+    const int blocks = 4 + (mode == 1 ? cdiv(Q * 9, 256) : 0);
     hipLaunchKernelGGL(input_param_grads_kernel, dim3(blocks), dim3(256), 0, st, dWeff, W, T, Q, n_slots, slot_major, mode, dW, dT);
     return check_launch("input_param_grads_kernel");
 }
