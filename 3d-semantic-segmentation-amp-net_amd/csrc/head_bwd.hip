@@ -57,12 +57,20 @@ __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd 
 #pragma unroll
             for (int c = 0; c < HEAD_MAX_CLASSES; ++c) dreg[c] = (ok && c < a.C) ? a.dlogits[((size_t)b * a.C + c) * a.P + p] : 0.f;
         }
+        // the next eight rows are requested before the current eight are processed (register double buffer)
+        float zn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zn[u] = a.z3[(size_t)min(r0 + u, a.R - 1) * 64 + k];
 #pragma unroll 1
         for (int i0 = 0; i0 < 64; i0 += 8) {
             if (r0 + i0 >= a.R) break;
             float zv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) zv[u] = a.z3[(size_t)min(r0 + i0 + u, a.R - 1) * 64 + k];
+            for (int u = 0; u < 8; ++u) zv[u] = zn[u];
+            if (i0 + 8 < 64) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) zn[u] = a.z3[(size_t)min(r0 + i0 + 8 + u, a.R - 1) * 64 + k];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = r0 + i0 + u;
