@@ -23,12 +23,16 @@ class _EncoderFn(torch.autograd.Function):
         module, pt, bt, off, Q, total, mx, n_slots = meta
         ws = ops.Workspace()
         local, glob, feat_T, _ = ops.encoder_forward(pt, bt, x, off, Q, total, mx, n_slots, True, ws)
-        ctx.meta = (module, pt, off, Q, total, mx, n_slots, ws, x, local, feat_T)
+        # tensors go through save_for_backward: keeping an OUTPUT on ctx directly makes an output -> grad_fn -> ctx -> output cycle
+        # the garbage collector cannot break, i.e. the whole activation workspace leaks when the backward never runs
+        ctx.save_for_backward(x, local, feat_T)
+        ctx.meta = (module, pt, off, Q, total, mx, n_slots, ws)
         return local, glob, feat_T
 
     @staticmethod
     def backward(ctx, d_local, d_glob, d_ft):
-        module, pt, off, Q, total, mx, n_slots, ws, x, local, feat_T = ctx.meta
+        module, pt, off, Q, total, mx, n_slots, ws = ctx.meta
+        x, local, feat_T = ctx.saved_tensors
         named = dict(module.named_parameters())
         grads = {n: torch.empty_like(named[n]) for n in P.ENC_PARAMS}
         gt = ops.PointerTable(P.ENC_PARAMS, grads, "encoder gradients")
@@ -52,12 +56,14 @@ class _HeadFn(torch.autograd.Function):
         module, pt, bt, cent, off, mask, B, W, total, mx, n_classes, p_drop, seed = meta
         ws = ops.Workspace()
         logits, _, _ = ops.head_forward(pt, bt, gl, lo, cent, off, mask, B, W, total, mx, n_classes, True, p_drop, seed, ws)
-        ctx.meta = (module, pt, cent, off, B, W, total, mx, n_classes, p_drop, seed, ws, lo)
+        ctx.save_for_backward(lo)
+        ctx.meta = (module, pt, cent, off, B, W, total, mx, n_classes, p_drop, seed, ws)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        module, pt, cent, off, B, W, total, mx, n_classes, p_drop, seed, ws, lo = ctx.meta
+        module, pt, cent, off, B, W, total, mx, n_classes, p_drop, seed, ws = ctx.meta
+        lo, = ctx.saved_tensors
         table = module._param_table()
         named = dict(module.named_parameters())
         grads = {n: torch.empty_like(named[n]) for n in table}

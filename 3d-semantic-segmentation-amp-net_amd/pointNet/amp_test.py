@@ -6,12 +6,12 @@ per-file accuracy and per-class IoU, a CSV row appended to <out_path>/../IoU-res
 The reference pushes every cluster (they have different sizes) through the encoder in a Python loop and repeats /
 concatenates the attention tokens per point; here all clusters of a file are ONE ragged launch sequence."""
 import os
-import pickle
 import time
 
 import numpy as np
 import torch
 
+from .._safe_load import load_tensor_list
 from ..utils.get_metrics import get_accuracy, get_iou_obj
 from ..utils.utils import get_labels
 from .datasets import LidarDataset4Test
@@ -20,15 +20,11 @@ from .model.pointnetAtt import BasePointNet, SegmentationWithAttention
 CLASS_KEYS = ['bckg', 'tower', 'cables', 'low_veg', 'high_veg']
 
 
-def _load_list(path):
-    """The cluster pickles are lists of tensors.  torch's restricted unpickler reads files written with torch.save;
-    files written by the reference's kmeans_clustering (plain pickle.dump, utils/utils.py:526-533) need pickle.load,
-    which executes what the file says: only feed files you produced yourself."""
-    try:
-        return torch.load(path, weights_only=True)
-    except Exception:
-        with open(path, 'rb') as f:
-            return pickle.load(f)
+def _load_list(path, allow_pickle=None):
+    """The cluster pickles are lists of tensors: torch.save files load with torch's restricted unpickler; files written by the
+    reference's kmeans_clustering (plain pickle.dump, utils/utils.py:526-533) need full unpickling, which executes what the
+    file says and is therefore an explicit opt-in (allow_pickle=True or AMPNET_ALLOW_PICKLE=1) -- _safe_load.py."""
+    return load_tensor_list(path, allow_pickle)
 
 
 def segment_file(base_pointnet, segmen_net, clusters_list, centroids, device):
@@ -45,13 +41,14 @@ def segment_file(base_pointnet, segmen_net, clusters_list, centroids, device):
 
 
 def test(dataset_path, out_path, n_points, number_of_workers, model_checkpoint, path_list_files, cluster_dir='k_means_25',
-         device='cuda'):
+         device='cuda', allow_pickle=None):
     start = time.time()
     device = torch.device(device)
     checkpoint = torch.load(model_checkpoint, map_location=device, weights_only=True)
     with open(os.path.join(path_list_files, 'test_seg_files.txt')) as f:
         test_files = f.read().splitlines()
-    ds = LidarDataset4Test(dataset_path, task='segmentation', number_of_points=n_points, files=test_files, fixed_num_points=False)
+    ds = LidarDataset4Test(dataset_path, task='segmentation', number_of_points=n_points, files=test_files, fixed_num_points=False,
+                           allow_pickle=allow_pickle)
     loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=number_of_workers, drop_last=False)
     base_pointnet = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device=device)
     segmen_net = SegmentationWithAttention(256, 8, local_dim=64, num_classes=5, device=device)
@@ -65,8 +62,8 @@ def test(dataset_path, out_path, n_points, number_of_workers, model_checkpoint, 
     accuracy = []
     for pc, file_name in loader:
         name = file_name[0].split('/')[-1].split('.')[0]
-        clusters = _load_list(os.path.join(cluster_dir, name + '_clusters_list.pkl'))
-        centroids = _load_list(os.path.join(cluster_dir, name + '_centroids.pkl'))
+        clusters = _load_list(os.path.join(cluster_dir, name + '_clusters_list.pkl'), allow_pickle)
+        centroids = _load_list(os.path.join(cluster_dir, name + '_centroids.pkl'), allow_pickle)
         preds, targets = segment_file(base_pointnet, segmen_net, clusters, torch.as_tensor(centroids), device)
         accuracy.append(get_accuracy(preds.numpy(), targets.numpy(), {}, 'segmentation')['accuracy'])
         present = set(targets.numpy().reshape(-1).tolist())

@@ -7,7 +7,8 @@ reference's train_att (pointNet/self-attention/train_pointnet-attention.py:29-33
   writes  pointNet/checkpoints/model_<name>.pth (same dict keys) whenever the mean validation loss improves.
 
 Data parallel: launched under torch.distributed.run (one process per GPU) every rank trains on a rank-strided
-shard of the file list and gradients are all-reduced per step (RCCL); rank 0 logs and writes checkpoints."""
+shard of the file list and gradients are all-reduced per step (RCCL); epoch metrics (incl. the validation loss that
+drives the checkpoint decision) are reduced over all ranks; rank 0 logs and writes checkpoints."""
 import datetime
 import os
 import time
@@ -52,9 +53,27 @@ def _epoch(loader, train, pointnet, att_net, opt_p, opt_a, ce_loss, epoch):
         sums['loss'].append(metrics['loss'].item())
         sums['ce'].append(metrics['ce_loss'].item())
         sums['reg'].append(metrics['reg_loss'].item())
-    out = {k: float(np.mean(v)) if v else float('nan') for k, v in sums.items()}
-    out.update({'iou_' + k: float(np.nanmean(v)) if v else float('nan') for k, v in ious.items()})
-    return out
+    return reduce_epoch_metrics(sums, ious, device=next(pointnet.parameters()).device)
+
+
+def reduce_epoch_metrics(sums, ious, device=None):
+    """Per-batch metric lists of this rank -> epoch means over ALL ranks' batches (the reference's mean over batches,
+    train_pointnet-attention.py:280-312, with the per-class IoU as nanmean).  Under torch.distributed every rank contributes
+    (sum, count) pairs to one SUM all-reduce, so every rank sees the same validation loss and takes the same
+    checkpoint / early-stop decision; single process: plain means."""
+    keys = list(sums.keys()) + ['iou_' + k for k in ious.keys()]
+    vals = [np.asarray(v, dtype=np.float64) for v in sums.values()] + [np.asarray(v, dtype=np.float64) for v in ious.values()]
+    acc = np.zeros((len(keys), 2), dtype=np.float64)
+    for i, v in enumerate(vals):
+        ok = ~np.isnan(v)
+        acc[i] = (v[ok].sum(), ok.sum())
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.from_numpy(acc).to(device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        acc = t.cpu().numpy()
+    return {k: (float(a[0] / a[1]) if a[1] > 0 else float('nan')) for k, a in zip(keys, acc)}
 
 
 def train_att(task, dataset_folder, path_list_files, output_folder, n_points, batch_size, epochs, learning_rate,
@@ -82,6 +101,7 @@ def train_att(task, dataset_folder, path_list_files, output_folder, n_points, ba
 
     pointnet = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=GLOBAL_FEAT_SIZE, device=device)
     att_net = SegmentationWithAttention(GLOBAL_FEAT_SIZE, ATT_HEADS, num_classes=5, local_dim=64, device=device)
+    att_net.seed = (att_net.seed ^ (rank * 0x9E3779B9)) & 0xFFFFFFFF      # data parallel: every rank draws its own dropout masks
     c_weights = torch.FloatTensor([1, 2, 2, 1, 1]).to(device)
     ce_loss = torch.nn.CrossEntropyLoss(weight=c_weights, reduction='mean', ignore_index=-1)
     opt_p = FusedAdam(pointnet.parameters(), lr=learning_rate)

@@ -4,11 +4,12 @@
 On-disk formats (unchanged): `kmeans_<name>.pt` = torch tensor [n, >=10, w] with columns x, y, HAG, class, I, R, G,
 B, NIR, NDVI, ... (data_proc/3_kmeans.py:116); test files = pickled numpy [n, >=10] rows with the same columns."""
 import os
-import pickle
 
 import numpy as np
 import torch
 from torch.utils import data
+
+from .._safe_load import load_numpy_pickle
 
 NOISE_CLASSES = (30, 7, 2, 8, 13, 14)     # datasets.py:339-350, deleted in this order
 
@@ -70,11 +71,12 @@ class LidarDataset4Test(data.Dataset):
     POINT_DIMENSION = 2
 
     def __init__(self, dataset_folder, task='classification', number_of_points=None, files=None, fixed_num_points=True,
-                 c_sample=False):
+                 c_sample=False, allow_pickle=None):
         self.dataset_folder = dataset_folder
         self.task = task
         self.n_points = number_of_points
         self.files = files
+        self.allow_pickle = allow_pickle
         self.fixed_num_points = fixed_num_points
         self.classes_mapping = {}
         self.constrained_sampling = c_sample
@@ -85,11 +87,10 @@ class LidarDataset4Test(data.Dataset):
 
     def __getitem__(self, index):
         """-> (pc [n, 10] float32 ndarray: x, y, HAG, I, R, G, B, NIR, NDVI, class code; filename).
-        NOTE: the reference unpickles the file (pickle.load, datasets.py:499-502); only files you wrote yourself
-        should be fed here."""
+        The reference unpickles the file (pickle.load, datasets.py:499-502); here a restricted unpickler reads plain numpy
+        array pickles and anything else needs allow_pickle=True / AMPNET_ALLOW_PICKLE=1 (_safe_load.py)."""
         filename = self.paths_files[index]
-        with open(filename, 'rb') as f:
-            pc = np.asarray(pickle.load(f), dtype=np.float32)
+        pc = np.asarray(load_numpy_pickle(filename, self.allow_pickle), dtype=np.float32)
         pc = np.concatenate((pc[:, :3], pc[:, 4:10], pc[:, 3:4]), axis=1)
         pc[:, 0] = pc[:, 0] * 2 - 1
         pc[:, 1] = pc[:, 1] * 2 - 1

@@ -76,6 +76,8 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not torch.is_tensor(st["step"]):          # checkpoints written by torch < 1.12 keep Adam's step as a Python int
+                    st["step"] = torch.tensor(float(st["step"]))
                 st["step"] += 1
                 steps.add(int(st["step"].item()))
             if len(steps) != 1:

@@ -80,7 +80,7 @@ def pmc_traffic_for(name, rows=None):
         return None
     table = json.load(open(path))
     v = table.get("events", {}).get(name)
-    if not v or (rows is not None and table.get("workload_rows") != rows):
+    if not v or (rows is not None and v.get("workload_rows", table.get("workload_rows")) != rows):
         return None                                     # the counters were collected on a different batch
     return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
 
@@ -161,75 +161,142 @@ def cpu_baseline(mode, budget_s=20.0):
                 sample=f"{n} x ({Bc} samples x {N_WIN} windows x {N_POINTS} pts) {mode}, oracle torch-CPU fp32, {dt:.1f} s")
 
 
-def bench_fps(args, dev, rank, world, dist):
-    """BASELINE.json configs[4]: farthest-point sampling, 16 clouds x 8192 points -> 4096 samples per GPU
-    (data_proc/sample_fps.py:23-31 sizes).  Clouds are independent: replicas only, no collective.
-    Roofline accounting: 16 B per (candidate, round) = 12 B xyz + 4 B running minimum."""
+def fps_leg(dev, B, steps, warmup, seed, cpu_baseline_s=0.0):
+    """BASELINE.json configs[4] on one GPU: farthest-point sampling, B clouds x 8192 points -> 4096 samples
+    (data_proc/sample_fps.py:23-31 sizes) and the build-defined k-NN grouping (k = 32) of those centres.
+    Roofline accounting: 16 B per (candidate, round) = 12 B xyz + 4 B running minimum; the cloud is
+    register-resident, so the true HBM traffic is the floor B*(N*12 + S*4) bytes (PMC: profiles/)."""
     synth = sub("synthetic")
     U = sub("utils.utils")
-    B, N, S = args.batch or 16, 8192, 4096
-    xyz = torch.from_numpy(synth.clouds(200 + rank, B, N)).to(dev)
-    for _ in range(max(args.warmup, 1)):
+    N, S, K = 8192, 4096, 32
+    xyz = torch.from_numpy(synth.clouds(seed, B, N)).to(dev)
+    for _ in range(max(warmup, 1)):
         idx = U.fps_indices(xyz, S)
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         idx = U.fps_indices(xyz, S)
     ev1.record()
     torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps              # the kernel runs on torch's current stream
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    # the second half of configs[4]: k-NN grouping (k = 32) of the FPS centres, build-defined spec (include/ampnet_hip.h)
-    K = 32
+    fps_ms = ev0.elapsed_time(ev1) / steps                     # the kernel runs on torch's current stream
     for _ in range(2):
-        grp = U.knn_indices(xyz, idx, K)
+        U.knn_indices(xyz, idx, K)
     torch.cuda.synchronize(dev)
     ev2, ev3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev2.record()
-    for _ in range(args.steps):
-        grp = U.knn_indices(xyz, idx, K)
+    for _ in range(steps):
+        U.knn_indices(xyz, idx, K)
     ev3.record()
     torch.cuda.synchronize(dev)
-    knn_ms = ev2.elapsed_time(ev3) / args.steps
+    knn_ms = ev2.elapsed_time(ev3) / steps
+    ach = float(B) * S * N * 16 / (fps_ms * 1e-3) / 1e9
+    out = {"workload": f"farthest-point sampling, {B} clouds x {N} points -> {S} samples", "ms": round(fps_ms, 4),
+           "selections_per_s": round(B * S / (fps_ms * 1e-3), 1), "us_per_round": round(fps_ms * 1e3 / (S - 1), 4),
+           "roofline": {"bound": "hbm", "kernel": "fps_kernel", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic_for("fps_kernel", B * N), "launch_ms": round(fps_ms, 4),
+                        "note": "algorithmic 16 B per (candidate, round); register-resident cloud: true HBM bytes = B*(N*12+S*4)"},
+           "knn": {"k": K, "ms": round(knn_ms, 4), "centres_per_s": round(B * S / (knn_ms * 1e-3), 1),
+                   "achieved_GBps": round(float(B) * S * N * 12 / (knn_ms * 1e-3) / 1e9, 1), "traffic": pmc_traffic_for("knn_kernel", B * N),
+                   "note": "build-defined exact k-NN (the reference has none); algorithmic 12 B per (candidate, centre), served from LDS"}}
+    if cpu_baseline_s > 0:
+        from oracle import fps_oracle
+        pc = synth.clouds(seed, 1, N)[0]
+        t1 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t1 < cpu_baseline_s and n < 8:
+            fps_oracle.fps_indices_c(pc, S)
+            n += 1
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(n * S / dtc, 1), "unit": "selections/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} clouds x {N} -> {S}, oracle/fps_oracle.c (scalar C), {dtc:.1f} s"}
+    return out
+
+
+def bench_fps(args, dev, rank, world, dist):
+    """--mode fps: BASELINE.json configs[4] as the headline line.  Clouds are independent: replicas only, no collective."""
+    B, S = args.batch or 16, 4096
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    leg = fps_leg(dev, B, args.steps, args.warmup, 200 + rank, 10.0 if (world == 1 and not args.no_cpu_baseline) else 0.0)
+    if dist is not None:
+        dist.barrier()
+    ms = leg["ms"]
+    if dist is not None:
+        tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
     if rank == 0:
-        alg_bytes = float(B) * S * N * 16
-        ach = alg_bytes / (kern_ms * 1e-3) / 1e9
-        out = {"metric": "FPS selections/sec (N=8192 -> 4096)", "value": round(world * B * S * args.steps / dt, 1), "unit": "selections/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        out = {"metric": "FPS selections/sec (N=8192 -> 4096)", "value": round(world * B * S / (ms * 1e-3), 1), "unit": "selections/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"farthest-point sampling, {B} clouds x {N} points -> {S} samples per GPU", "parallelism": f"replicas{world}"},
-               "roofline": {"bound": "hbm", "kernel": "fps_kernel<512,16>", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                            "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": None, "launch_ms": round(kern_ms, 4),
-                            "note": "algorithmic 16 B per (candidate, round); the cloud is register-resident, true HBM traffic is B*(N*12+S*4) bytes"}}
-        knn_bytes = float(B) * S * N * 12
-        out["knn"] = {"k": K, "ms": round(knn_ms, 4), "centres_per_s": round(B * S / (knn_ms * 1e-3), 1),
-                      "achieved_GBps": round(knn_bytes / (knn_ms * 1e-3) / 1e9, 1),
-                      "note": "build-defined exact k-NN (the reference has none); algorithmic 12 B per (candidate, centre), served from LDS"}
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import fps_oracle
-            pc = synth.clouds(200, 1, N)[0]
-            t1 = time.perf_counter()
-            n = 0
-            while time.perf_counter() - t1 < 10.0 and n < 8:
-                fps_oracle.fps_indices_c(pc, S)
-                n += 1
-            dtc = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(n * S / dtc, 1), "unit": "selections/s", "cores": 1, "kind": "port",
-                                   "sample": f"{n} clouds x {N} -> {S}, oracle/fps_oracle.c (scalar C), {dtc:.1f} s"}
+               "config": {"workload": leg["workload"] + " per GPU", "parallelism": f"replicas{world}"},
+               "us_per_round": leg["us_per_round"], "roofline": leg["roofline"], "knn": leg["knn"]}
+        if "cpu_baseline" in leg:
+            out["cpu_baseline"] = leg["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_loop_inclusive(enc, att, trainer_mod, B, dev, steps):
+    """PCIe-inclusive figure (never `value`): one drop-in train_loop call per step on a HOST batch exactly as collate_seq_padd
+    returns it -- upload (pageable memory), device augmentation kernel, the fused step, download of predictions and targets
+    (train_pointnet-attention.py:337-475 end to end)."""
+    synth, S = sub("synthetic"), sub("pointNet.amp_step")
+    pc, tg, cent, _ = synth.sample_batch(300, B, N_POINTS, max_w=N_WIN)
+    data = (torch.from_numpy(pc), torch.from_numpy(tg), ["f"] * B, torch.from_numpy(cent))
+    opt_p, opt_a = trainer_mod.FusedAdam(enc.parameters(), lr=1e-3), trainer_mod.FusedAdam(att.parameters(), lr=1e-3)
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
+    np.random.seed(0)
+    for _ in range(2):
+        S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N_WIN * N_POINTS / dt, 1),
+            "note": "host batch (pageable) -> upload + ampnet_augment_f32 + fused step + preds/targets download; informational"}
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` from a plain shell: run this script as N ranks under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1), pass the ranks' output through (rank 0 prints the JSON line) and return the launcher's
+    exit code, non-zero when any rank failed.  Returns instead of exec'ing: a process that may have touched the GPU must never
+    be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(rank, world):
+    """No GPU: every rank joins a gloo group, all-reduces (rank + 1), rank 0 prints one JSON line.  AMPNET_BENCH_FAIL_RANK=r
+    makes rank r exit non-zero first (the launcher must report that)."""
+    if os.environ.get("AMPNET_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    total = float(rank + 1)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([total], dtype=torch.float64)
+        dist.all_reduce(t)
+        total = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "ranks": world, "backend": "gloo", "rank_sum": total}), flush=True)
 
 
 def main():
@@ -240,16 +307,24 @@ def main():
     ap.add_argument("--mode", choices=["fwd", "train", "fps", "auto"], default="auto")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational legs (train_loop_inclusive, fps)")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
                     help="MFMA operand precision of the forward per-point layers (fp32 accumulate, fp32 backward either way)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU yet
+        # (importing torch does not initialise HIP), and the ranks are fresh children, never an exec of this process.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE to let bench.py start them)")
+    if args.dry_run:
+        return dry_run(rank, world)
     # one rank per GPU; AMPNET_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, with AMPNET_DIST_BACKEND=gloo) folds the ranks onto
     # the devices that exist
     ndev = torch.cuda.device_count()
@@ -257,6 +332,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("AMPNET_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
@@ -365,6 +441,22 @@ def main():
                     "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1),
                     "note": "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32"}
 
+    # the data-parallel exchange on its own: one SUM all-reduce per network over its flat gradient buffer (4.8 MB in all)
+    ar_ms = None
+    if dist is not None and mode == "train":
+        bufs = [torch.zeros_like(b) for b in step()["grad_bufs"]]
+        sync()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            for b in bufs:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(dev)
+        ar_ms = (time.perf_counter() - t4) / args.steps * 1e3
+    incl = fps = None
+    if mode == "train" and world == 1 and not args.no_extra_legs:
+        incl = train_loop_inclusive(enc, att, trainer_mod, B, dev, max(args.steps // 2, 3))
+        fps = fps_leg(dev, 16, max(args.steps // 2, 3), 1, 200, 0.0 if args.no_cpu_baseline else 5.0)
+
     if rank == 0:
         pts_step = B * N_WIN * N_POINTS
         value = world * pts_step * args.steps / dt
@@ -382,6 +474,8 @@ def main():
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "bf16_forward_mode": bf16_leg,
+            "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
+            "train_loop_inclusive": incl, "fps": fps,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))

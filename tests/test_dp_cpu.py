@@ -91,3 +91,53 @@ def test_grad_store_views_alias_flat_buffer():
         assert p.grad.shape == p.shape and p.grad.data_ptr() % 256 == st.flat.data_ptr() % 256
     st.flat.fill_(2.0)
     assert all(float(p.grad.sum()) == 2.0 * p.numel() for p in enc.parameters())
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                                  # a cold shell: bench.py must start its own ranks
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` from a plain shell starts two ranks (torch.distributed.run, 127.0.0.1), relays rank 0's JSON line
+    and exits 0; --dry-run keeps the GPU out of it (gloo), the rendezvous and launcher are the ones the GPU run uses."""
+    import json
+    r = _run_bench({}, "--gpus", "2", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "ranks": 2, "backend": "gloo", "rank_sum": 3.0}
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _run_bench({"AMPNET_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--dry-run")
+    assert r.returncode != 0
+
+
+def _metrics_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A = sub("pointNet.amp_train")
+        sums = dict(loss=[1.0 + rank, 2.0 + rank], acc=[0.5 * (rank + 1)] * 2)
+        ious = dict(tower=[float("nan"), 0.25 * (rank + 1)], bckg=[0.5, 0.75] if rank == 0 else [float("nan")] * 2)
+        torch.save(A.reduce_epoch_metrics(sums, ious), os.path.join(out_dir, f"m{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_epoch_metrics_are_reduced_over_ranks(tmp_path):
+    """Every rank must see the same validation loss (checkpoint decision, amp_train.py): mean over all ranks' batches."""
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.spawn(_metrics_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    m0 = torch.load(tmp_path / "m0.pt", weights_only=True)
+    m1 = torch.load(tmp_path / "m1.pt", weights_only=True)
+    assert m0 == m1
+    assert m0["loss"] == pytest.approx((1 + 2 + 2 + 3) / 4) and m0["acc"] == pytest.approx(0.75)
+    assert m0["iou_tower"] == pytest.approx((0.25 + 0.5) / 2) and m0["iou_bckg"] == pytest.approx(0.625)

@@ -162,3 +162,30 @@ def test_checkpoint_roundtrip_keys(tmp_path, params):
     enc2 = M.BasePointNet(point_dimension=3, return_local_features=True, device="cpu")
     enc2.load_state_dict(ck["base_pointnet"])                  # strict: every reference key present, nothing extra
     assert torch.equal(enc2.conv_6.weight, enc.conv_6.weight)
+
+
+def test_pickled_inputs_need_an_explicit_opt_in(tmp_path, monkeypatch):
+    """a file torch's restricted unpickler rejects must not silently fall through to pickle.load."""
+    import pickle
+    SL = sub("_safe_load")
+    arr = np.arange(12, dtype=np.float32).reshape(3, 4)
+    p_np = tmp_path / "a.pkl"
+    with open(p_np, "wb") as f:
+        pickle.dump(arr, f)
+    assert np.array_equal(SL.load_numpy_pickle(str(p_np)), arr)          # plain numpy pickles load, nothing else is resolved
+
+    class Evil:
+        def __reduce__(self):
+            return (os.path.join, ("executed", "payload"))
+    p_bad = tmp_path / "b.pkl"
+    with open(p_bad, "wb") as f:
+        pickle.dump([Evil()], f)
+    monkeypatch.delenv("AMPNET_ALLOW_PICKLE", raising=False)
+    for loader in (SL.load_numpy_pickle, SL.load_tensor_list):
+        with pytest.raises(Exception) as e:
+            loader(str(p_bad))
+        assert "AMPNET_ALLOW_PICKLE" in str(e.value)
+    assert SL.load_tensor_list(str(p_bad), allow_pickle=True) == ["executed/payload"]      # the explicit opt-in
+    p_t = tmp_path / "c.pkl"
+    torch.save([torch.ones(2, 3)], p_t)
+    assert torch.equal(SL.load_tensor_list(str(p_t))[0], torch.ones(2, 3))

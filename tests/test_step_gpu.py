@@ -34,6 +34,19 @@ def _models(synth, params, dropout=0.3):
     return enc, att
 
 
+def _grad_rtol(tag, key):
+    """Relative bar of one gradient tensor against the reference's own fp32 gradient (tests/golden/step.npz).
+    Tensors whose gradient does not travel back through a T-Net FC BatchNorm (the head, and the encoder layers after the
+    feature transform) are well conditioned: 1e-3.  Everything upstream of bn_4 / bn_5 of a T-Net (they normalise over only
+    B = 16 rows of near-identical pooled features) carries the fp32 noise of the reference itself, up to 2e-2 from a
+    float64 evaluation (tests/test_oracle_golden.py): 3e-2."""
+    if tag == "att":
+        return 1e-3
+    if key.split(".")[0] in ("conv_3", "conv_4", "conv_5", "conv_6", "bn_3", "bn_4", "bn_5", "bn_6"):
+        return 1e-3
+    return 3e-2
+
+
 def _batch(golden, synth):
     g = golden("step")
     B, N, W = [int(v) for v in g["meta"]]
@@ -110,12 +123,12 @@ def test_train_loop_two_steps_match_reference(golden, synth, params):
                 for k, p in mod.named_parameters():
                     gn = g[f"s1_{tag}_gnorm/{k}"]
                     got = p.grad.double()
-                    # the reference's fp32 gradients are themselves up to 2e-2 from float64 here (B = 16)
-                    assert abs(got.norm().item() - gn[0]) <= 3e-2 * gn[0] + 1e-5 * gtot, (k, got.norm().item(), gn[0])
+                    rt_g = _grad_rtol(tag, k)
+                    assert abs(got.norm().item() - gn[0]) <= rt_g * gn[0] + 1e-5 * gtot, (k, got.norm().item(), gn[0])
                     key = f"s1_{tag}_grad/{k}"
                     if key in g.files:
                         err = np.linalg.norm(got.cpu().numpy() - g[key].astype(np.float64))
-                        assert err <= 3e-2 * gn[0] + 1e-5 * gtot, (k, err, gn[0])
+                        assert err <= rt_g * gn[0] + 1e-5 * gtot, (k, err, gn[0])
         for tag, mod in (("enc", enc), ("att", att)):
             for k, p in mod.named_parameters():
                 ps = g[f"s{step}_{tag}_psum/{k}"]
@@ -166,7 +179,7 @@ def test_reference_style_loop_with_autograd(golden, synth, params):
     for tag, mod in (("enc", enc), ("att", att)):
         for k, p in mod.named_parameters():
             gn = g[f"s1_{tag}_gnorm/{k}"]
-            assert abs(p.grad.double().norm().item() - gn[0]) <= 3e-2 * gn[0] + 1e-5 * gtot, k
+            assert abs(p.grad.double().norm().item() - gn[0]) <= _grad_rtol(tag, k) * gn[0] + 1e-5 * gtot, k
             ps = g[f"s1_{tag}_psum/{k}"]
             np.testing.assert_allclose(p.detach().double().abs().sum().item(), ps[1], rtol=2e-4,
                                        atol=2.1e-3 * max(1.0, 0.02 * p.numel()), err_msg=k)
