@@ -157,8 +157,15 @@ def cpu_baseline(mode, budget_s=20.0):
             break
     dt = time.perf_counter() - t0
     pts = n * Bc * N_WIN * N_POINTS
-    return dict(value=round(pts / dt, 1), unit="points/s", cores=cores, kind="port",
-                sample=f"{n} x ({Bc} samples x {N_WIN} windows x {N_POINTS} pts) {mode}, oracle torch-CPU fp32, {dt:.1f} s")
+    out = dict(value=round(pts / dt, 1), unit="points/s", cores=cores, kind="port",
+               sample=f"{n} x ({Bc} samples x {N_WIN} windows x {N_POINTS} pts) {mode}, oracle torch-CPU fp32, {dt:.1f} s")
+    # the port timed next to the reference's own train_loop in the build container (tests/golden/time_reference.py): port / reference
+    ratio_file = os.path.join(ROOT, "tests", "golden", "reference_vs_port.json")
+    if os.path.exists(ratio_file):
+        r = json.load(open(ratio_file))
+        key = "ratio_train" if mode == "train" else "ratio_eval"
+        out["reference_ratio"] = {"port_over_reference": r[key], "measured": f"build container, {r['threads']} threads, B={r['B']}, tests/golden/time_reference.py"}
+    return out
 
 
 def fps_leg(dev, B, steps, warmup, seed, cpu_baseline_s=0.0):
