@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libampnet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -57,19 +57,20 @@ def lib():
     return l
 
 
-PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16_train": 2}
 
 
 def set_matrix_precision(mode):
-    """'fp32' (default, exact fp32 products: the mode the parity figures hold in) or 'bf16' (the forward per-point layers
-    round their MFMA operands to bf16, fp32 accumulation; include/ampnet_hip.h: ampnet_set_matrix_precision)."""
+    """'fp32' (default, exact fp32 products: the mode the parity figures hold in), 'bf16' (the forward per-point layers
+    round their MFMA operands to bf16, fp32 accumulation) or 'bf16_train' (forward and the fused backward of those layers;
+    include/ampnet_hip.h: ampnet_set_matrix_precision)."""
     if mode not in PRECISIONS:
         raise AmpnetError(f"unknown matrix precision {mode!r}: one of {sorted(PRECISIONS)}")
     check(lib().ampnet_set_matrix_precision(PRECISIONS[mode]), "ampnet_set_matrix_precision")
 
 
 def get_matrix_precision():
-    return "bf16" if lib().ampnet_get_matrix_precision() == 1 else "fp32"
+    return {0: "fp32", 1: "bf16", 2: "bf16_train"}[lib().ampnet_get_matrix_precision()]
 
 
 def check(rc, what):

@@ -197,13 +197,25 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 // fixed order -- a quarter of the dependent (load -> barrier -> multiply) trips per launch.
 constexpr int SG_SK = 4;
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
-                                                                 const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int accumulate)
+struct SgProblem {
+    int M, N, K, ta, tb, lda, ldb, ldc, accumulate;
+    const float *A, *B;
+    float *C;
+};
+struct SgArgs {
+    SgProblem p[2];      // blockIdx.z picks the problem: independent products of one backward step share a launch
+};
+
+__global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
 {
     __shared__ float sA[SG_SK][32][33], sB[SG_SK][32][33];     // [group][k][m], [group][k][n]
+    const SgProblem &g = args.p[blockIdx.z];
+    const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb;
+    const bool TA = g.ta != 0, TB = g.tb != 0;
+    const float *__restrict__ A = g.A, *__restrict__ B = g.B;
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= M || n0 >= N) return;                             // the grid covers the larger of the two problems (uniform per block)
     // group g owns the k tiles g, g + SK, ... (32 deep each)
     float acc[2][2] = {};
     float ra[4], rb[4];
@@ -211,12 +223,10 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(int M, int N, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
-            int m, k;
-            if (TA) { m = e % 32; k = e / 32; } else { k = e % 32; m = e / 32; }
+            const int m = TA ? e % 32 : e / 32, k = TA ? e / 32 : e % 32;
             const int gm = m0 + m, gk = k0 + k;
             ra[i] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
-            int n, k2;
-            if (TB) { k2 = e % 32; n = e / 32; } else { n = e % 32; k2 = e / 32; }
+            const int n = TB ? e / 32 : e % 32, k2 = TB ? e % 32 : e / 32;
             const int gn = n0 + n, gk2 = k0 + k2;
             rb[i] = (gn < N && gk2 < K) ? (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn]) : 0.f;
         }
@@ -268,26 +278,47 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(int M, int N, 
                 float v = 0.f;
 #pragma unroll
                 for (int g2 = 0; g2 < SG_SK; ++g2) v += red[(g2 * 4 + i * 2 + j) * 256 + tid];
-                float *d = C + (size_t)gm * ldc + gn;
-                *d = accumulate ? *d + v : v;
+                float *d = g.C + (size_t)gm * g.ldc + gn;
+                *d = g.accumulate ? *d + v : v;
             }
         }
     }
 }
 
+static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
+{
+    SgArgs a;
+    int gx = 1, gy = 1;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const SgProblem &p = probs[i];
+        AMPNET_REQUIRE(p.A && p.B && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "sgemm_small: bad arguments");
+        a.p[i] = p;
+        gx = cdiv(p.N, 32) > gx ? cdiv(p.N, 32) : gx;
+        gy = cdiv(p.M, 32) > gy ? cdiv(p.M, 32) : gy;
+        flops += 2.0 * p.M * p.N * p.K;
+        bytes += 4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
+    }
+    if (n == 1) a.p[1] = a.p[0];
+    ProfScope prof("sgemm_small", flops, bytes, st);
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3(gx, gy, n), dim3(256 * SG_SK), 0, st, a);
+    return check_launch("sgemm_small_kernel");
+}
+
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                 int accumulate, hipStream_t st)
 {
-    AMPNET_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1, "sgemm_small: bad arguments");
-    dim3 grid(cdiv(N, 32), cdiv(M, 32));
-    char name[64];
-    snprintf(name, sizeof(name), "sgemm_small");
-    ProfScope prof(name, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), st);
-    if (transA && transB) hipLaunchKernelGGL((sgemm_small_kernel<true, true>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else if (transA) hipLaunchKernelGGL((sgemm_small_kernel<true, false>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else if (transB) hipLaunchKernelGGL((sgemm_small_kernel<false, true>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    else hipLaunchKernelGGL((sgemm_small_kernel<false, false>), grid, dim3(256 * SG_SK), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
-    return check_launch("sgemm_small_kernel");
+    const SgProblem p = {M, N, K, transA, transB, lda, ldb, ldc, accumulate, A, B, C};
+    return sgemm_launch(&p, 1, st);
+}
+
+// the weight gradient dW = G^T X ([N_out, N_in] = [rows, N_out]^T [rows, N_in]) and the data gradient dX = G W of one linear layer
+// on [rows, *] activations, one launch (the two products are independent)
+int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
+                     float *dX, int lddx, hipStream_t st)
+{
+    const SgProblem p[2] = {{n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW}, {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX}};
+    return sgemm_launch(p, 2, st);
 }
 
 // ----------------------------------------------------------------------------------------------------

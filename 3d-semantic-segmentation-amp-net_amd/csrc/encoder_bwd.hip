@@ -295,19 +295,16 @@ struct EncBwd {
         TRY(fc_act(zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, Q, 256, per, b.a1, st));
         TRY(fc_act(zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, Q, 128, per, b.a2, st));
         // fc_3: z3 = a2 W3^T + b3
-        TRY(sgemm_small(1, 0, kk, 128, Q, g3, kk, b.a2, 128, G[pbase + TP_FC3_W], 128, 0, st));
+        TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st));
         TRY(colsum(g3, Q, kk, G[pbase + TP_FC3_B], st));
-        TRY(sgemm_small(0, 0, Q, 128, kk, g3, kk, P[pbase + TP_FC3_W], 128, b.da2, 128, 0, st));
         TRY(fc_bn_bwd(b.da2, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per, 128, b.g2,
                       b.bn[bn0 + 4].slot_ab, st));
         // fc_2
-        TRY(sgemm_small(1, 0, 128, 256, Q, b.g2, 128, b.a1, 256, G[pbase + TP_FC2], 256, 0, st));
-        TRY(sgemm_small(0, 0, Q, 256, 128, b.g2, 128, P[pbase + TP_FC2], 256, b.da1, 256, 0, st));
+        TRY(sgemm_linear_bwd(Q, 128, 256, b.g2, 128, b.a1, 256, P[pbase + TP_FC2], 256, G[pbase + TP_FC2], 256, b.da1, 256, st));
         TRY(fc_bn_bwd(b.da1, zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per, 256, b.g1,
                       b.bn[bn0 + 3].slot_ab, st));
         // fc_1 on the pooled features
-        TRY(sgemm_small(1, 0, 256, 256, Q, b.g1, 256, pooled, 256, G[pbase + TP_FC1], 256, 0, st));
-        TRY(sgemm_small(0, 0, Q, 256, 256, b.g1, 256, P[pbase + TP_FC1], 256, b.d_pool, 256, 0, st));
+        TRY(sgemm_linear_bwd(Q, 256, 256, b.g1, 256, pooled, 256, P[pbase + TP_FC1], 256, G[pbase + TP_FC1], 256, b.d_pool, 256, st));
         return AMPNET_OK;
     }
 };

@@ -2,17 +2,15 @@
 //
 // Replaces utils/utils.py:889-933 of the reference.  The algorithm is S-1 dependent rounds; a round is
 //   d[j] = min(d[j], |p_last - p_j|^2)  for every point, then argmax_j d[j] (first index on ties).
-// Mapping to CDNA4: the cloud lives in REGISTERS for the whole kernel (thread t owns points t, t+T, ...:
-// coalesced 4-byte loads once, 12 B xyz + 4 B running minimum per point = the 16 B per (candidate, round)
-// the roofline counts, served from the register file instead of HBM), a round costs
-//   VALU update (branch-free)  ->  64-lane argmax by DPP row operations + 4 readlanes  ->  one LDS slot per wave
-//   ->  ONE barrier  ->  16-lane DPP fold of the slots
-// and the winner's coordinates travel with its slot, so no thread ever indexes its register array at run
-// time and nothing is re-read from global memory.  Slots are double-buffered so a round needs one barrier.
+// Mapping to CDNA4: the cloud lives in REGISTERS for the whole kernel (12 B xyz + 4 B running minimum per point = the
+// 16 B per (candidate, round) the roofline counts, served from the register file instead of HBM); a round is VALU work
+// (12 instructions per point) plus ONE dependent chain: wave reduction of the value by 32-bit DPP -> one LDS slot per
+// wave -> one barrier -> 16-lane DPP fold -> one LDS read of the winner's coordinates (fps_kernel below).  Clouds of more
+// than 16384 points keep only the running minima in registers and stream the coordinates from L2 (fps_stream_kernel).
 //
 // Bit parity: distances are float32 ((dx*dx + dy*dy) + dz*dz) with one rounding per operation -- this file
-// is compiled with -ffp-contract=off and the pragma below repeats it; picked points carry -1 so that
-// min(d, -1) keeps them out for good (every true distance is >= 0); ties go to the lowest index.
+// is compiled with -ffp-contract=off and the pragma below repeats it; ties go to the lowest index.
+#include <cstdlib>
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -67,19 +65,59 @@ __device__ __forceinline__ void row4_max64(uint32_t &hi, uint32_t &lo)
     dpp_max64<0x4E>(hi, lo);
 }
 
-// LXYZ: a copy of the cloud's coordinates lives in LDS (n * 12 bytes <= 144 KB), so a round only carries (distance,
-// index) through the reductions and reads the winner's coordinates with three broadcast LDS loads; otherwise the
-// coordinates travel with the per-thread / per-wave winner.
-template <int T, int P, bool LXYZ>
+// ---- 32-bit DPP reductions (value only): one VALU instruction per step -------------------------------------------
+// Running minima are compared as INTEGERS: the bit pattern of a float >= 0 orders like the float, and the negative markers
+// (-2 padding, -3 / -4 "nothing yet") are negative integers, below every real distance.  Integer max needs no NaN
+// canonicalisation (fmaxf costs an extra v_max per operand) and folds into v_max_i32_dpp.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);     // full masks + bound_ctrl: `old` is dead, the move folds into the consumer
+}
+// maximum over the 64 lanes, valid in lane 63 (rows of 16 by quad / mirror steps, then row_bcast:15 and row_bcast:31)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(v));           // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v));           // row_mirror: every lane of a row holds the row's maximum
+    v = max(v, dpp_i32<0x142, 0xA>(v));      // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_i32<0x143, 0xC>(v));      // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// v_min_f32 as it stands: fminf() lowers to a canonicalising v_max_f32 x, x in front of every v_min (IEEE minNum for signalling
+// NaNs), one more VALU instruction per point and round.  Distances are never NaN here.
+__device__ __forceinline__ float min_f32(float a, float b)
+{
+    float m;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+
+// One workgroup per cloud, the cloud in REGISTERS (thread t owns the P consecutive points t*P ..), a copy of the
+// coordinates in LDS as float4 (LDSXYZ, n <= 9216) or re-read from global memory / L2 for the winner only.
+// A round = P x (distance, running minimum, strict-> argmax: 12 VALU per point)
+//   -> wave maximum of the VALUE by six 32-bit DPP steps + one readlane; ballot of the lanes that hold it, lowest lane,
+//      readlane of its k: the wave's (maximum, lowest index) in scalars, one 8-byte LDS slot per wave
+//   -> ONE barrier (slots double-buffered by round parity)
+//   -> every lane reads slot lane & (FOLD - 1); log2(FOLD) DPP steps give the maximum, as many more the lowest index among its holders
+//   -> one broadcast ds_read_b128 of the winner's coordinates.
+// Picked points need no marker: a picked point's running minimum is exactly 0 after the next update (its distance to itself),
+// so while the maximum M is > 0 no picked point can win.  M == 0 means every point left is a duplicate of a picked one and
+// the running minima can never change again: the remaining picks are the unpicked indices in ascending order (what the
+// reference's argmax over an all-zero `dists[points_left]` returns, utils.py:927-931), emitted from a bitmap of the picks.
+// STAMP (diagnostic build, ampnet_fps_round_stamps): thread 0 writes s_memtime after the update, after the barrier, after the
+// fold and after the coordinate read of every round into a buffer nothing else reads.
+template <int T, int P, bool LDSXYZ, bool STAMP = false>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int n, int ld, int s,
-                                                int32_t *__restrict__ idx)
+                                                int32_t *__restrict__ idx, unsigned long long *__restrict__ stamps = nullptr)
 {
     constexpr int NW = T / WAVE;
     static_assert(NW <= 16, "one row of 16 lanes folds the wave slots");
-    extern __shared__ __attribute__((aligned(16))) float s_cloud[];      // LXYZ: x[n], y[n], z[n]
-    // per-wave slot = winner key (+ its coordinates), two generations (one barrier per round)
-    __shared__ uint32_t s_hi[2][16], s_lo[2][16];
-    __shared__ float s_x[2][16], s_y[2][16], s_z[2][16];
+    extern __shared__ __attribute__((aligned(16))) float s_cloud[];      // LDSXYZ: float4[n]
+    __shared__ uint2 s_slot[2][16];                                      // (bits of the wave's maximum, its lowest index)
+    __shared__ uint32_t s_picked[16384 / 32];
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
@@ -90,33 +128,24 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
     float px[P], py[P], pz[P], dist[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        const int j = tid + k * T;
+        const int j = tid * P + k;
         const bool ok = j < n;
         px[k] = ok ? cloud[(size_t)j * ld + 0] : 0.f;
         py[k] = ok ? cloud[(size_t)j * ld + 1] : 0.f;
         pz[k] = ok ? cloud[(size_t)j * ld + 2] : 0.f;
-        dist[k] = ok ? __builtin_inff() : -2.0f;   // -2: padding lanes never win, never change
-        if (LXYZ && ok) {
-            s_cloud[j] = px[k];
-            s_cloud[n + j] = py[k];
-            s_cloud[2 * n + j] = pz[k];
-        }
+        dist[k] = ok ? __builtin_inff() : -2.0f;   // -2: padding never wins (M > 0 in every round that picks), never changes
+        if (LDSXYZ && ok) *reinterpret_cast<float4 *>(s_cloud + 4 * (size_t)j) = make_float4(px[k], py[k], pz[k], 0.f);
     }
-    // seed: point 0 (utils.py:907-908)
+    for (int w = tid; w < 16384 / 32; w += T) s_picked[w] = w == 0 ? 1u : 0u;      // seed: point 0 (utils.py:907-908)
+    if (tid < 32) s_slot[tid >> 4][tid & 15] = make_uint2(__float_as_uint(-4.0f), 0x7FFFFFFFu);   // unused slots never win
     float lx = cloud[0], ly = cloud[1], lz = cloud[2];
-    if (tid == 0) {
-        out[0] = 0;
-        dist[0] = -1.0f;
-    }
-    if (tid < 32) {                                  // unused slots of the 16-lane fold never win
-        s_hi[tid >> 4][tid & 15] = 0u;
-        s_lo[tid >> 4][tid & 15] = 0u;
-    }
+    if (tid == 0) out[0] = 0;
     __syncthreads();
 
-    for (int r = 1; r < s; ++r) {
+    int r = 1;
+    for (; r < s; ++r) {
         // ---- update + thread-local argmax, branch-free: ascending k and a strict compare keep the lowest index ----
-        float bd = -3.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        float bd = -3.0f;
         int bi = 0;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -124,70 +153,142 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
             const float dy = ly - py[k];
             const float dz = lz - pz[k];
             const float d = (dx * dx + dy * dy) + dz * dz;
-            const float m = fminf(d, dist[k]);          // picked (-1) and padding (-2) stay as they are
+            const float m = min_f32(d, dist[k]);
             dist[k] = m;
             const bool take = m > bd;
             bd = take ? m : bd;
             bi = take ? k : bi;
-            if (!LXYZ) {
-                bx = take ? px[k] : bx;
-                by = take ? py[k] : by;
-                bz = take ? pz[k] : bz;
-            }
         }
-        const uint32_t bhi = fkey(bd), blo = ~(uint32_t)(tid + bi * T);
-        // ---- 64-lane argmax: DPP inside the four rows of 16, then four scalars ----
-        uint32_t whi = bhi, wlo = blo;
+        if (STAMP && tid == 0) stamps[4 * (size_t)r + 0] = __builtin_amdgcn_s_memtime();
+        // ---- the wave's maximum and the lowest index that holds it (indices ascend with the lane, then with k) ----
+        const int bdi = __float_as_int(bd);
+        const int wm = wave_max_i32(bdi);
+        const unsigned long long holders = __ballot(bdi == wm);
+        const int wl = __ffsll((long long)holders) - 1;
+        const int wk = __builtin_amdgcn_readlane(bi, wl);
+        const int g = r & 1;
+        if (lane == 0) s_slot[g][wave] = make_uint2((uint32_t)wm, (uint32_t)((wave * WAVE + wl) * P + wk));
+        __syncthreads();
+        if (STAMP && tid == 0) stamps[4 * (size_t)r + 1] = __builtin_amdgcn_s_memtime();
+        // ---- fold the slots (replicated in every row of 16 lanes): maximum, then lowest index among its holders ----
+        constexpr int FOLD = NW <= 4 ? 4 : (NW <= 8 ? 8 : 16);          // slots replicated every FOLD lanes: every lane ends with the result
+        const uint2 sl = s_slot[g][lane & (FOLD - 1)];
+        const int sm = (int)sl.x;
+        int Mi = sm;
+        Mi = max(Mi, dpp_i32<0xB1>(Mi));
+        Mi = max(Mi, dpp_i32<0x4E>(Mi));
+        if (NW > 4) Mi = max(Mi, dpp_i32<0x141>(Mi));
+        if (NW > 8) Mi = max(Mi, dpp_i32<0x140>(Mi));
+        int gi = sm == Mi ? (int)sl.y : 0x7FFFFFFF;
+        gi = min(gi, dpp_i32<0xB1>(gi));
+        gi = min(gi, dpp_i32<0x4E>(gi));
+        if (NW > 4) gi = min(gi, dpp_i32<0x141>(gi));
+        if (NW > 8) gi = min(gi, dpp_i32<0x140>(gi));
+        const float M = __int_as_float(Mi);
+        if (STAMP && tid == 0) stamps[4 * (size_t)r + 2] = __builtin_amdgcn_s_memtime() + (gi & 0);   // after the fold
+        if (!(M > 0.0f)) break;                                  // uniform: only duplicates of picked points are left
+        if (LDSXYZ) {
+            const float4 c = *reinterpret_cast<const float4 *>(s_cloud + 4 * (size_t)gi);
+            lx = c.x;
+            ly = c.y;
+            lz = c.z;
+        } else {
+            lx = cloud[(size_t)gi * ld + 0];
+            ly = cloud[(size_t)gi * ld + 1];
+            lz = cloud[(size_t)gi * ld + 2];
+        }
+        if (tid == 0) {
+            out[r] = gi;
+            s_picked[gi >> 5] |= 1u << (gi & 31);                // only this thread writes the bitmap
+        }
+        if (STAMP && tid == 0) stamps[4 * (size_t)r + 3] = __builtin_amdgcn_s_memtime() + (__float_as_int(lx) & 0);   // coordinates landed
+    }
+    if (r < s) {                                                 // the all-duplicates tail (see above); rare, serial
+        __syncthreads();
+        if (tid == 0) {
+            for (int j = 0; j < n && r < s; ++j)
+                if (!((s_picked[j >> 5] >> (j & 31)) & 1u)) out[r++] = j;
+        }
+    }
+}
+
+// n > 16384: nothing of the cloud fits on chip for the whole kernel, so a round STREAMS it: coordinates and running minima
+// live in a structure-of-arrays workspace in global memory (x[n], y[n], z[n], d[n] per cloud; 16 B per point, it stays in
+// the XCD's L2), thread t walks points t, t + T, ... with coalesced loads, rewrites a running minimum only when it changed,
+// and the reduction carries 64-bit (distance, ~index) keys (lowest index on ties for any ownership).  A picked point is
+// retired by its owner during the next round's walk (its minimum becomes -1: every real distance is >= 0).
+template <int T>
+__global__ __launch_bounds__(T) void fps_stream_kernel(float *__restrict__ soa, int n, int s, int32_t *__restrict__ idx)
+{
+    __shared__ uint32_t s_hi[2][16], s_lo[2][16];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const float *X = soa + (size_t)blockIdx.x * 4 * n, *Y = X + n, *Z = Y + n;
+    float *D = soa + (size_t)blockIdx.x * 4 * n + 3 * (size_t)n;
+    int32_t *out = idx + (size_t)blockIdx.x * s;
+    float lx = X[0], ly = Y[0], lz = Z[0];
+    int last = 0;
+    if (tid == 0) out[0] = 0;
+    if (tid < 32) {
+        s_hi[tid >> 4][tid & 15] = 0u;
+        s_lo[tid >> 4][tid & 15] = 0u;
+    }
+    __syncthreads();
+    for (int r = 1; r < s; ++r) {
+        float bd = -3.0f;
+        int bj = 0;
+#pragma unroll 4
+        for (int j = tid; j < n; j += T) {
+            const float old = D[j];
+            const float dx = lx - X[j];
+            const float dy = ly - Y[j];
+            const float dz = lz - Z[j];
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float m = j == last ? -1.0f : fminf(d, old);       // picked points stay at -1: min(d, -1) = -1
+            if (m != old) D[j] = m;
+            const bool take = m > bd;                                 // ascending j, strict: lowest index of the thread
+            bd = take ? m : bd;
+            bj = take ? j : bj;
+        }
+        uint32_t whi = fkey(bd), wlo = ~(uint32_t)bj;
         row16_max64(whi, wlo);
         uint32_t ghi = (uint32_t)__builtin_amdgcn_readlane((int)whi, 0), glo = (uint32_t)__builtin_amdgcn_readlane((int)wlo, 0);
         smax64(ghi, glo, (uint32_t)__builtin_amdgcn_readlane((int)whi, 16), (uint32_t)__builtin_amdgcn_readlane((int)wlo, 16));
         smax64(ghi, glo, (uint32_t)__builtin_amdgcn_readlane((int)whi, 32), (uint32_t)__builtin_amdgcn_readlane((int)wlo, 32));
         smax64(ghi, glo, (uint32_t)__builtin_amdgcn_readlane((int)whi, 48), (uint32_t)__builtin_amdgcn_readlane((int)wlo, 48));
         const int g = r & 1;
-        if (LXYZ) {
-            if (lane == 0) {
-                s_hi[g][wave] = ghi;
-                s_lo[g][wave] = glo;
-            }
-        } else if (blo == glo && bhi == ghi) {   // exactly one lane of the wave owns the wave's winner (indices are unique)
-            s_hi[g][wave] = bhi;
-            s_lo[g][wave] = blo;
-            s_x[g][wave] = bx;
-            s_y[g][wave] = by;
-            s_z[g][wave] = bz;
+        if (lane == 0) {
+            s_hi[g][wave] = ghi;
+            s_lo[g][wave] = glo;
         }
         __syncthreads();
-        // ---- fold the wave slots: lane l of every row reads slot l & 15, one row-of-16 DPP max, every lane has it ----
-        constexpr int FOLD = NW <= 4 ? 4 : (NW <= 8 ? 8 : 16);          // slots replicated every FOLD lanes
-        const uint32_t mhi = s_hi[g][lane & (FOLD - 1)], mlo = s_lo[g][lane & (FOLD - 1)];
-        uint32_t fhi = mhi, flo = mlo;
-        if (FOLD == 4) row4_max64(fhi, flo);
-        else if (FOLD == 8) row8_max64(fhi, flo);
-        else row16_max64(fhi, flo);
-        const int gi = (int)~flo;
-        if (LXYZ) {
-            lx = s_cloud[gi];
-            ly = s_cloud[n + gi];
-            lz = s_cloud[2 * n + gi];
-        } else {
-            const unsigned long long own = __ballot(mlo == flo && mhi == fhi);
-            const int gw = __ffsll((long long)own) - 1;        // slot of the winner (lanes 0..15 carry the slots)
-            lx = s_x[g][gw];
-            ly = s_y[g][gw];
-            lz = s_z[g][gw];
-        }
-        if (tid == 0) out[r] = gi;
-        // retire the winner in its owner's registers: compile-time k, run-time predicate
-        const int own_t = gi % T, own_k = gi / T;
-#pragma unroll
-        for (int k = 0; k < P; ++k) dist[k] = (tid == own_t && k == own_k) ? -1.0f : dist[k];
+        uint32_t fhi = s_hi[g][lane & 15], flo = s_lo[g][lane & 15];
+        row16_max64(fhi, flo);
+        last = (int)~flo;
+        lx = X[last];
+        ly = Y[last];
+        lz = Z[last];
+        if (tid == 0) out[r] = last;
+    }
+}
+
+// [n_clouds, n, ld] rows -> [n_clouds, 4, n] structure of arrays x, y, z, running minimum (the stream kernel's workspace)
+__global__ void fps_soa_kernel(const float *__restrict__ xyz, int n, int ld, float *__restrict__ soa)
+{
+    const int c = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float *p = xyz + ((size_t)c * n + j) * ld;
+        float *o = soa + (size_t)c * 4 * n;
+        o[j] = p[0];
+        o[n + j] = p[1];
+        o[2 * (size_t)n + j] = p[2];
+        o[3 * (size_t)n + j] = j == 0 ? -1.0f : __builtin_inff();       // seed: point 0 is picked (utils.py:907-908)
     }
 }
 
 template <int T, int P>
 static int launch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, hipStream_t st)
 {
-    const size_t lds = (size_t)n * 3 * sizeof(float);
+    const size_t lds = (size_t)n * 4 * sizeof(float);
     if (lds <= 144 * 1024) {
         static bool attr_set = false;
         auto kern = fps_kernel<T, P, true>;
@@ -196,9 +297,9 @@ static int launch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t 
             if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "fps: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(n_clouds), dim3(T), lds, st, xyz, n, ld, s, idx);
+        hipLaunchKernelGGL(kern, dim3(n_clouds), dim3(T), lds, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr);
     } else {
-        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(n_clouds), dim3(T), 0, st, xyz, n, ld, s, idx);
+        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(n_clouds), dim3(T), 0, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr);
     }
     return check_launch("fps_kernel");
 }
@@ -218,21 +319,52 @@ __global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t 
 
 }  // namespace ampnet
 
-extern "C" int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *stream)
+extern "C" size_t ampnet_fps_workspace_bytes(int n_clouds, int n)
+{
+    if (n_clouds < 1 || n <= AMPNET_FPS_RESIDENT_MAX) return 0;
+    return (size_t)n_clouds * 4 * (size_t)n * sizeof(float);
+}
+
+extern "C" int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *workspace,
+                              size_t workspace_bytes, void *stream)
 {
     using namespace ampnet;
     AMPNET_REQUIRE(xyz && idx, "ampnet_fps_f32: null pointer");
     AMPNET_REQUIRE(n_clouds >= 1 && n >= 1 && ld >= 3, "ampnet_fps_f32: bad shape n_clouds=%d n=%d ld=%d", n_clouds, n, ld);
     AMPNET_REQUIRE(s >= 1 && s <= n, "ampnet_fps_f32: n_samples=%d must be in [1, n=%d]", s, n);
-    AMPNET_REQUIRE(n <= 16384, "ampnet_fps_f32: n=%d exceeds 16384 points per cloud", n);
+    AMPNET_REQUIRE(n <= AMPNET_FPS_MAX_POINTS, "ampnet_fps_f32: n=%d exceeds %d points per cloud", n, AMPNET_FPS_MAX_POINTS);
     hipStream_t st = (hipStream_t)stream;
+    if (n > AMPNET_FPS_RESIDENT_MAX) {
+        const size_t need = ampnet_fps_workspace_bytes(n_clouds, n);
+        if (!workspace || workspace_bytes < need) return fail(AMPNET_E_WORKSPACE, "ampnet_fps_f32: n=%d needs a workspace of %zu B (ampnet_fps_workspace_bytes)", n, need);
+        float *soa = reinterpret_cast<float *>(workspace);
+        hipLaunchKernelGGL(fps_soa_kernel, dim3(cdiv(n, 256) < 256 ? cdiv(n, 256) : 256, n_clouds), dim3(256), 0, st, xyz, n, ld, soa);
+        hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(n_clouds), dim3(1024), 0, st, soa, n, s, idx);
+        return check_launch("fps_stream_kernel");
+    }
     if (n <= 256) return launch<256, 1>(xyz, n_clouds, n, ld, s, idx, st);
     if (n <= 1024) return launch<256, 4>(xyz, n_clouds, n, ld, s, idx, st);
     if (n <= 2048) return launch<512, 4>(xyz, n_clouds, n, ld, s, idx, st);
-    // 16 points per thread from 4096 points on: a round is bound by the argmax reduction, and half the waves halve it
     if (n <= 4096) return launch<512, 8>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 8192) return launch<512, 16>(xyz, n_clouds, n, ld, s, idx, st);
+    static const int t8k = [] { const char *e = getenv("AMPNET_FPS_T8K"); return e ? atoi(e) : 512; }();      // tuning hook
+    if (n <= 8192) {
+        if (t8k == 1024) return launch<1024, 8>(xyz, n_clouds, n, ld, s, idx, st);
+        if (t8k == 768) return launch<768, 11>(xyz, n_clouds, n, ld, s, idx, st);
+        return launch<512, 16>(xyz, n_clouds, n, ld, s, idx, st);
+    }
     return launch<1024, 16>(xyz, n_clouds, n, ld, s, idx, st);
+}
+
+extern "C" int ampnet_fps_round_stamps(const float *xyz, int n, int ld, int s, int32_t *idx, unsigned long long *stamps, void *stream)
+{
+    using namespace ampnet;
+    AMPNET_REQUIRE(xyz && idx && stamps, "ampnet_fps_round_stamps: null pointer");
+    AMPNET_REQUIRE(n > 4096 && n <= 8192 && ld >= 3 && s >= 1 && s <= n, "ampnet_fps_round_stamps: built for one cloud of 4097..8192 points");
+    auto kern = fps_kernel<512, 16, true, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "fps: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(1), dim3(512), (size_t)n * 16, (hipStream_t)stream, xyz, n, ld, s, idx, stamps);
+    return check_launch("fps_kernel (stamps)");
 }
 
 extern "C" int ampnet_gather_rows_f32(const float *src, const int32_t *idx, int n_clouds, int n, int ld, int s,

@@ -404,23 +404,19 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     }
     // ---- token path: gbias = g2tok W2[:, 64:]^T + b2 ; g2tok = ctx Wo^T + bo ; qkv = tok Wi^T + bi -------------
     const float *d_gbias = b.dgb;                                                           // [Q, 128]
-    TRY(sgemm_small(1, 0, 128, 256, Q, d_gbias, 128, f.g2, 256, G[HP_CONV2_W] + 64, 320, 0, st));
-    TRY(sgemm_small(0, 0, Q, 256, 128, d_gbias, 128, P[HP_CONV2_W] + 64, 320, b.d_g2, 256, 0, st));
-    TRY(sgemm_small(1, 0, 256, 256, Q, b.d_g2, 256, f.ctx, 256, G[HP_OUTPROJ_W], 256, 0, st));
+    TRY(sgemm_linear_bwd(Q, 128, 256, d_gbias, 128, f.g2, 256, P[HP_CONV2_W] + 64, 320, G[HP_CONV2_W] + 64, 320, b.d_g2, 256, st));
+    TRY(sgemm_linear_bwd(Q, 256, 256, b.d_g2, 256, f.ctx, 256, P[HP_OUTPROJ_W], 256, G[HP_OUTPROJ_W], 256, b.d_ctx, 256, st));
     TRY(colsum(b.d_g2, Q, 256, G[HP_OUTPROJ_B], st));
-    TRY(sgemm_small(0, 0, Q, 256, 256, b.d_g2, 256, P[HP_OUTPROJ_W], 256, b.d_ctx, 256, 0, st));
     hipLaunchKernelGGL(attention_core_bwd_kernel, dim3(B, HEAD_HEADS), dim3(64), 0, st, f.qkv, f.probs, b.d_ctx, b.d_qkv, W, drop_p,
                        drop_base(seed, 0));
     TRY(check_launch("attention_core_bwd_kernel"));
-    TRY(sgemm_small(1, 0, 768, 256, Q, b.d_qkv, 768, f.tok, 256, G[HP_INPROJ_W], 256, 0, st));
+    TRY(sgemm_linear_bwd(Q, 768, 256, b.d_qkv, 768, f.tok, 256, P[HP_INPROJ_W], 256, G[HP_INPROJ_W], 256, d_gl, 256, st));   // d_tok = d_gl = d_pos
     TRY(colsum(b.d_qkv, Q, 768, G[HP_INPROJ_B], st));
-    TRY(sgemm_small(0, 0, Q, 256, 768, b.d_qkv, 768, P[HP_INPROJ_W], 256, d_gl, 256, 0, st));   // d_tok = d_gl = d_pos
     // ---- positional encoding: pos = leaky(cent W1^T + b1) W2^T + b2 --------------------------------------------
     hipLaunchKernelGGL(posenc_hidden_kernel, dim3(cdiv(Q * 16, 64)), dim3(64), 0, st, centroids, P[HP_FC1_W], P[HP_FC1_B], Q, b.hid, b.slope);
     TRY(check_launch("posenc_hidden_kernel"));
-    TRY(sgemm_small(1, 0, 256, 16, Q, d_gl, 256, b.hid, 16, G[HP_FC2_W], 16, 0, st));
+    TRY(sgemm_linear_bwd(Q, 256, 16, d_gl, 256, b.hid, 16, P[HP_FC2_W], 16, G[HP_FC2_W], 16, b.d_hid, 16, st));
     TRY(colsum(d_gl, Q, 256, G[HP_FC2_B], st));
-    TRY(sgemm_small(0, 0, Q, 16, 256, d_gl, 256, P[HP_FC2_W], 16, b.d_hid, 16, 0, st));
     hipLaunchKernelGGL(mul_inplace_kernel, dim3(cdiv(Q * 16, 256)), dim3(256), 0, st, b.d_hid, b.slope, Q * 16);
     TRY(check_launch("mul_inplace_kernel"));
     TRY(sgemm_small(1, 0, 16, 2, Q, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, 0, st));

@@ -236,6 +236,7 @@ int pw_bwd_blocks(int Q, int n_slots, int max_rows);     // blocks_per_slot for 
 bool pw_bwd_supported(int cx, int cy);
 int pw_bwd_item_rows();
 int pw_bwd_fused(const PwBwd &a, hipStream_t st);
+int pw_bwd_fused_bf16(const PwBwd &a, hipStream_t st);     // the same pass with bf16 MFMA operands (pw_bwd_bf16.hip); pw_bwd_fused dispatches
 
 // dst[i] (= or +=) sum_q part[q * stride + i], i < n, fixed order; dst row-remap for strided destinations:
 // element i = (r, c) with c < cols -> dst[r * ld_dst + c]
@@ -337,5 +338,8 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st);
 // C[M, N] = op(A) * op(B) (+ C if accumulate); row-major, small problems (T-Net FC layers, attention projections)
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                 int accumulate, hipStream_t st);
+// backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W
+int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
+                     float *dX, int lddx, hipStream_t st);
 
 }  // namespace ampnet

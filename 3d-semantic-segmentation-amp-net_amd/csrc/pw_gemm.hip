@@ -189,10 +189,43 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
     }
+    // fp32 path: the operands of a k step (weights bv[t] of every column tile, prologue-transformed activations av) are read /
+    // computed ONE STEP AHEAD, under the MFMAs of the current step: the matrix pipe never waits on an LDS round trip (PMC before
+    // this: matrix pipes busy 67 % of the cycles, two exposed ds_read latencies per 16 MFMAs).  The chain runs across k blocks,
+    // tiles (the weights do not depend on the tile) and is primed once per block of rows (the prologue constants may change).
+    auto pro_apply = [&](f32x4 v, const f32x4 &sc, const f32x4 &sh, int row, int k0) -> f32x4 {
+        if (PRO) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+            if (PRO == 2) {
+                const uint32_t e0 = (uint32_t)row * (uint32_t)CIN + (uint32_t)k0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? v[i] * dscale : 0.f;
+            }
+        }
+        return v;
+    };
+    auto arow_of = [&](int t_) -> int {
+        const int row0_ = row_begin + t_ * 32;
+        return row0_ + min(r, min(32, row_end - row0_) - 1);
+    };
+    f32x4 bv[NT], av = {0.f, 0.f, 0.f, 0.f};
+    if (!BF && tile < ntiles) {
+        const int k0 = 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (PRO) {
+            sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
+            sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
+        }
+        av = pro_apply(a_cur[0], sc, sh, arow_of(tile), k0);
+    }
     for (; tile < ntiles; tile += PW_NW) {
         const int row0 = row_begin + tile * 32;
         const int valid = min(32, row_end - row0);
         const int arow = row0 + min(r, valid - 1);
+        const int arow_next = (tile + PW_NW < ntiles) ? arow_of(tile + PW_NW) : arow;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -244,28 +277,31 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[t], acc[t], 0, 0, 0);
                 }
             }
+            if (!BF) {
 #pragma unroll
-            for (int j = 0; j < (BF ? 0 : 4); ++j) {
-                const int k0 = 32 * kb + 8 * j + 4 * h;
-                f32x4 av = a_cur[j];
-                if (PRO) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
+                for (int j = 0; j < 4; ++j) {
+                    // the step after this one: (kb, j + 1), or step 0 of the next k block / of this wave's next tile
+                    const bool wrap = j == 3;
+                    const int k0n = (wrap ? (32 * (kb + 1)) % CIN : 32 * kb + 8 * (j + 1)) + 4 * h;
+                    const int row_n = (wrap && kb == NBLK - 1) ? arow_next : arow;
+                    f32x4 sc_n = {1.f, 1.f, 1.f, 1.f}, sh_n = {0.f, 0.f, 0.f, 0.f}, av_n = av;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) av[i] = fmaxf(fmaf(av[i], sc[i], sh[i]), 0.f);
-                    if (PRO == 2) {
-                        const uint32_t e0 = (uint32_t)arow * (uint32_t)CIN + (uint32_t)k0;
+                    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) av[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? av[i] * dscale : 0.f;
+                        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t][i], acc[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);      // the four MFMAs first ...
+                        // ... then, in their shadow: tile t's weights are dead, fetch the next step's; the prologue constants are
+                        // requested two tiles before the VALU that consumes them
+                        bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0n);
+                        if (PRO && t == 0) {
+                            sc_n = *reinterpret_cast<const f32x4 *>(sPro + k0n);
+                            sh_n = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0n);
+                        }
+                        if (t == (NT > 2 ? 2 : NT - 1)) av_n = pro_apply(wrap ? a_nxt[0] : a_cur[(j + 1) & 3], sc_n, sh_n, row_n, k0n);
+                        __builtin_amdgcn_sched_barrier(0);      // keep this order: the scheduler would sink the reads to their use
                     }
+                    av = av_n;
                 }
-                f32x4 bv[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t][i], acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
@@ -414,7 +450,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
 template <int CIN, int NT, int PRO, bool POOL>
 static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
-    return matrix_precision() == AMPNET_PRECISION_BF16 ? launch_pw_y<CIN, NT, PRO, POOL, true>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+    return matrix_precision() != AMPNET_PRECISION_F32 ? launch_pw_y<CIN, NT, PRO, POOL, true>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
 }
 
 // the (prologue, pool) variants each shape is actually used with; anything else is an argument error

@@ -31,8 +31,13 @@ def fps_indices(xyz, n_samples):
     if not (1 <= n_samples <= N):
         raise IndexError(f"fps: n_samples={n_samples} out of range for {N} points")   # reference: IndexError at :928
     idx = torch.empty((B, n_samples), dtype=torch.int32, device=x.device)
+    L = _lib.lib()
+    L.ampnet_fps_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_fps_workspace_bytes(B, N)              # 0 for register-resident clouds (N <= 16384)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     with torch.cuda.device(x.device):
-        rc = _lib.lib().ampnet_fps_f32(_lib.ptr(x), B, N, D, n_samples, _lib.ptr(idx), _lib.stream_ptr(x.device))
+        rc = L.ampnet_fps_f32(_lib.ptr(x), B, N, D, n_samples, _lib.ptr(idx), _lib.ptr(ws), ctypes.c_size_t(need),
+                              _lib.stream_ptr(x.device))
     _lib.check(rc, "ampnet_fps_f32")
     return idx[0] if single else idx
 

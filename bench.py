@@ -317,8 +317,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational legs (train_loop_inclusive, fps)")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
-                    help="MFMA operand precision of the forward per-point layers (fp32 accumulate, fp32 backward either way)")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
+                    help="MFMA operand precision: fp32 (headline), bf16 = forward per-point layers, bf16_train = forward + fused backward (fp32 accumulate)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -427,26 +427,32 @@ def main():
         fwd_ms = (time.perf_counter() - t2) / args.steps * 1e3
         enc.train(); att.train()
 
-    # informational leg: the same train step with bf16 MFMA operands in the forward layers (never the headline value)
-    bf16_leg = None
-    if mode == "train" and args.precision == "fp32":
-        sub("_lib").set_matrix_precision("bf16")
-        for _ in range(2):
-            step()
-        sync()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dt_bf = time.perf_counter() - t3
+    # informational legs (never the headline value): the same train step with bf16 MFMA operands in the forward per-point layers,
+    # and in forward + fused backward (BASELINE.json configs[2] names bf16 MFMA; tests/test_bf16_gpu.py states what holds there)
+    def precision_leg(prec, note):
+        sub("_lib").set_matrix_precision(prec)
+        try:
+            for _ in range(2):
+                step()
+            sync()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            dt_bf = time.perf_counter() - t3
+        finally:
+            sub("_lib").set_matrix_precision("fp32")
         if dist is not None:
             tt = torch.tensor([dt_bf], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_bf = float(tt.item())
-        sub("_lib").set_matrix_precision("fp32")
-        bf16_leg = {"ms_per_step": round(dt_bf / args.steps * 1e3, 4),
-                    "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1),
-                    "note": "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32"}
+        return {"ms_per_step": round(dt_bf / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1), "note": note}
+
+    bf16_leg = bf16_train_leg = None
+    if mode == "train" and args.precision == "fp32":
+        bf16_leg = precision_leg("bf16", "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32")
+        bf16_train_leg = precision_leg("bf16_train", "forward AND fused backward of the per-point layers on bf16 MFMA operands (f32 accumulate, "
+                                                     "f32 tensors in HBM, f32 BatchNorm statistics / sums); gradient bar: tests/test_bf16_gpu.py")
 
     # the data-parallel exchange on its own: one SUM all-reduce per network over its flat gradient buffer (4.8 MB in all)
     ar_ms = None
@@ -472,7 +478,8 @@ def main():
             "metric": "train points/sec + forward ms/window (N=2048)" if mode == "train" else "forward points/sec + forward ms/window (N=2048)",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16 forward MFMA operands, f32 accumulate / statistics / backward", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 forward MFMA operands, f32 accumulate / statistics / backward",
+                                          "bf16_train": "bf16 MFMA operands (forward + fused backward), f32 accumulate / statistics / tensors"}[args.precision], "data": "synthetic",
             "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"dp{world}"},
@@ -480,7 +487,7 @@ def main():
             "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
-            "bf16_forward_mode": bf16_leg,
+            "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
             "train_loop_inclusive": incl, "fps": fps,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPNET_ABI_VERSION 1
+#define AMPNET_ABI_VERSION 2
 
 enum {
     AMPNET_OK = 0,
@@ -49,8 +49,19 @@ const char *ampnet_last_error(void);
  * xyz: [n_clouds, n, ld] fp32, columns 0..2 = x,y,z (ld >= 3 lets the caller pass whole rows).
  * idx: [n_clouds, s] int32, selection order; idx[c][0] == 0 (utils.py:907-908).
  * Bit-exact with the reference: float32 ((dx*dx + dy*dy) + dz*dz), running minimum, first maximum.
- * 1 <= s <= n <= 16384.                                                                           */
-int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *stream);
+ * 1 <= s <= n <= AMPNET_FPS_MAX_POINTS.  Clouds of up to AMPNET_FPS_RESIDENT_MAX points are register-resident and need no
+ * workspace (workspace may be NULL); larger clouds (the raw 100 x 100 m tiles of data_proc/sample_fps.py:23-26) stream
+ * their coordinates and running minima from a structure-of-arrays copy in `workspace` (ampnet_fps_workspace_bytes(n_clouds, n) bytes).  */
+#define AMPNET_FPS_RESIDENT_MAX 16384
+#define AMPNET_FPS_MAX_POINTS (1 << 24)
+size_t ampnet_fps_workspace_bytes(int n_clouds, int n);
+int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* diagnostic build of the 8192-point kernel (one cloud): stamps[4 r + {0,1,2,3}] = s_memtime of thread 0 after the update,
+ * after the barrier, after the slot fold and after the winner's coordinates landed in round r (FPS round anatomy).
+ * The stamps go to a buffer nothing else reads; idx is the ordinary result.                                              */
+int ampnet_fps_round_stamps(const float *xyz, int n, int ld, int s, int32_t *idx, unsigned long long *stamps, void *stream);
 
 /* rows gather: out[c][i][:] = src[c][idx[c][i]][:]  (the `pc[sample_inds]` of utils.py:933)         */
 int ampnet_gather_rows_f32(const float *src, const int32_t *idx, int n_clouds, int n, int ld, int s,
@@ -186,6 +197,11 @@ int ampnet_knn_f32(const float *xyz, int n_clouds, int n, int ld, const int32_t 
  * BatchNorm statistics, loss and the whole backward stay fp32.  BASELINE.json config 3 ("bf16 MFMA MLP/attention").   */
 #define AMPNET_PRECISION_F32 0
 #define AMPNET_PRECISION_BF16 1
+/* AMPNET_PRECISION_BF16_TRAIN: the forward of AMPNET_PRECISION_BF16 AND the fused backward of the shared per-point layers
+ * (weight gradient dW = g^T a and data gradient dy = g W of one pass, csrc/pw_bwd_bf16.hip) with bf16 operands: g = dy P1 + z P2 + P3,
+ * the recomputed activation a and the weights are formed in fp32 and rounded once; accumulation, BatchNorm-backward sums, the
+ * K <= 12 input layers, the T-Net FC layers, the attention and every tensor in HBM stay fp32.                                   */
+#define AMPNET_PRECISION_BF16_TRAIN 2
 int ampnet_set_matrix_precision(int mode);
 int ampnet_get_matrix_precision(void);
 

@@ -241,5 +241,7 @@ def keep_mask(seed, stream, n, p):
     base = _mix32(np.array([(seed + stream * 0x9E3779B9) & 0xFFFFFFFF], dtype=np.uint64))[0]
     idx = np.arange(n, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
     h = _mix32(idx ^ base)
-    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    # the probability crosses the C ABI as a float (include/ampnet_hip.h: `float drop_p`), so the threshold is that of the
+    # float32-rounded value: float(0.3f) * 2^32 and 0.3 * 2^32 differ by 51 -- one element in 8e7 (found at B = 32, N = 2048)
+    thr = np.uint64(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
     return (h >= thr)

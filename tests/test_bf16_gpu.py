@@ -93,3 +93,98 @@ def test_train_step_close_to_fp32(synth, params, bf16_mode):
     assert abs(nb - nf) <= 0.1 * nf and cos > 0.8, (nb, nf, cos)
     k = "a.conv_4.weight"
     assert (gb[k] - gf[k]).norm().item() <= 1e-2 * gf[k].norm().item()
+
+
+# ---- bf16_train: the fused backward of the shared layers on bf16 MFMA operands too (csrc/pw_bwd_bf16.hip) -------------------
+def _rel(a, b):
+    return (a.double() - b.double()).norm().item() / (b.double().norm().item() + 1e-30)
+
+
+@pytest.mark.parametrize("B,W,N", [(8, 3, 600), (16, 9, 2048)])
+def test_bf16_backward_kernels_close_to_fp32_encoder(synth, params, B, W, N):
+    """The SAME fp32 forward (workspace recomputed for each run), then the encoder backward once with fp32 and once with bf16
+    operands in the fused layer kernels.  What a bf16 product can promise per layer is a relative 2^-8 per term; the weight
+    gradients of the layers whose gradient path has not crossed a T-Net FC BatchNorm yet (conv_6 .. conv_3: first in the backward
+    walk) must agree to 2e-2, everything within the conditioning-limited 0.25 / cosine 0.97 of this model (module docstring)."""
+    ops, L = sub("ops"), sub("_lib")
+    p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
+    b0 = synth.make_buffers(5, params.ENC_BUFFERS)
+    Q = B * W
+    x = synth.windows(300 + B, Q, N)
+    xd = torch.from_numpy(x.reshape(-1, 9)).cuda()
+    off, total, mx = ops.window_offsets([N] * Q, xd.device)
+    r1 = torch.from_numpy(synth.uniform(401, (Q * N, 64), -1, 1)).cuda()
+    r2 = torch.from_numpy(synth.uniform(402, (Q, 256), -1, 1)).cuda()
+    r3 = torch.from_numpy(synth.uniform(403, (Q, 64, 64), -1, 1)).cuda()
+    res = {}
+    try:
+        for mode in ("fp32", "bf16_train"):
+            b = {k: torch.from_numpy(v.copy()).cuda() for k, v in b0.items()}
+            grads = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+            pt, bt = ops.PointerTable(params.ENC_PARAMS, p, "p"), ops.PointerTable(params.ENC_BUFFERS, b, "b")
+            gt = ops.PointerTable(params.ENC_PARAMS, grads, "g")
+            fws, bws = ops.Workspace(), ops.Workspace()
+            L.set_matrix_precision("fp32")
+            local, glob, ft, _ = ops.encoder_forward(pt, bt, xd, off, Q, total, mx, W, True, fws)
+            L.set_matrix_precision(mode)
+            ops.encoder_backward(pt, gt, xd, off, Q, total, mx, W, local, ft, r1, r2, r3, fws, bws)
+            torch.cuda.synchronize()
+            res[mode] = {k: v.clone() for k, v in grads.items()}
+    finally:
+        L.set_matrix_precision("fp32")
+    gf, gb = res["fp32"], res["bf16_train"]
+    assert all(torch.isfinite(v).all() for v in gb.values())
+    assert any(not torch.equal(gf[k], gb[k]) for k in gf), "the bf16 backward did not run"
+    rel = {k: _rel(gb[k], gf[k]) for k in gf}
+    first = ["conv_6.weight", "conv_5.weight", "conv_4.weight", "conv_3.weight", "bn_5.weight", "bn_4.weight", "bn_3.weight"]
+    print("bf16 backward vs fp32, relative error:", {k: f"{rel[k]:.2e}" for k in first + ["conv_2.weight", "feature_transform.conv_2.weight", "input_transform.conv_2.weight"]})
+    for k in first:
+        assert rel[k] <= 2e-2, (k, rel[k])
+    nb = np.sqrt(sum((gb[k].double() ** 2).sum().item() for k in gf))
+    nf = np.sqrt(sum((gf[k].double() ** 2).sum().item() for k in gf))
+    cos = sum((gb[k].double() * gf[k].double()).sum().item() for k in gf) / (nb * nf)
+    print(f"all encoder gradients: |bf16| / |fp32| = {nb / nf:.4f}, cosine {cos:.4f}, worst tensor {max(rel, key=rel.get)} {max(rel.values()):.2e}")
+    assert abs(nb - nf) <= 0.1 * nf and cos > 0.97, (nb, nf, cos)
+
+
+def test_bf16_backward_kernels_close_to_fp32_head(synth, params):
+    """Head backward (conv_3 with the dropout mask, conv_2 with the per-window token bias) with bf16 operands against the fp32
+    kernels on the same fp32 forward: every head gradient and both outputs (d_lo, d_gl) within 2e-2."""
+    ops, L = sub("ops"), sub("_lib")
+    p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(7, params.HEAD_PARAMS).items()}
+    b0 = synth.make_buffers(7, params.HEAD_BUFFERS)
+    B, W, npc = 8, 3, [700, 300, 513]
+    Pp = sum(npc)
+    gl = synth.uniform(41, (W, B, 256), 0.0, 2.0)
+    lo = synth.uniform(42, (B, Pp, 64), -1.0, 1.0)
+    cent = synth.uniform(43, (B, W, 2), -1.0, 1.0)
+    tg = synth.randint(44, (B, Pp), -1, 5)
+    gld = torch.from_numpy(np.ascontiguousarray(gl.transpose(1, 0, 2)).reshape(B * W, 256)).cuda()
+    lod = torch.from_numpy(lo.reshape(-1, 64)).cuda()
+    centd = torch.from_numpy(cent).cuda()
+    off, total, mx = ops.window_offsets(npc * B, lod.device)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0]).cuda()
+    res = {}
+    try:
+        for mode in ("fp32", "bf16_train"):
+            b = {k: torch.from_numpy(v.copy()).cuda() for k, v in b0.items()}
+            grads = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+            pt, bt = ops.PointerTable(params.HEAD_PARAMS, p, "p"), ops.PointerTable(params.HEAD_BUFFERS, b, "b")
+            gt = ops.PointerTable(params.HEAD_PARAMS, grads, "g")
+            fws, bws = ops.Workspace(), ops.Workspace()
+            L.set_matrix_precision("fp32")
+            logits, _, loss = ops.head_forward(pt, bt, gld, lod, centd, off, None, B, W, total, mx, 5, True, 0.3, 99, fws,
+                                               targets=torch.from_numpy(tg), class_w=cw)
+            dlog = ops.ce_backward(logits, torch.from_numpy(tg).cuda(), cw, loss)
+            L.set_matrix_precision(mode)
+            d_lo, d_gl = ops.head_backward(pt, gt, lod, centd, off, B, W, total, mx, 5, 0.3, 99, dlog, fws, bws)
+            torch.cuda.synchronize()
+            res[mode] = dict({k: v.clone() for k, v in grads.items()}, __d_lo=d_lo.clone(), __d_gl=d_gl.clone())
+    finally:
+        L.set_matrix_precision("fp32")
+    gf, gb = res["fp32"], res["bf16_train"]
+    assert any(not torch.equal(gf[k], gb[k]) for k in gf), "the bf16 backward did not run"
+    rel = {k: _rel(gb[k], gf[k]) for k in gf if gf[k].double().norm().item() > 1e-12}
+    print("bf16 head backward vs fp32, relative error:", {k: f"{v:.2e}" for k, v in rel.items()})
+    for k, v in rel.items():
+        assert v <= 2e-2, (k, v)

@@ -44,6 +44,48 @@ def test_fps_matches_oracle_shapes(synth, n, s, ld):
         assert np.array_equal(got[c], want), f"cloud {c}: first mismatch at {np.argmax(got[c] != want)}"
 
 
+@pytest.mark.parametrize("n,s,ld", [(16385, 700, 3), (20000, 8192, 13), (40000, 1000, 3), (60000, 8192, 4)])
+def test_fps_large_clouds_match_oracle(synth, n, s, ld):
+    """Raw tiles before the first FPS stage have any size (data_proc/sample_fps.py:23-26: `if pc.shape[0] > 8192: fps(pc, 8192)`):
+    clouds of more than 16384 points stream their coordinates (fps_stream_kernel) -- same indices as the C oracle, bit for bit."""
+    U = sub("utils.utils")
+    pc = synth.uniform(2000 + n, (2, n, ld), -1.0, 1.0)
+    pc[1, :, :3] = np.round(pc[1, :, :3] * 16) / 16      # 33^3 grid cells for >= 16385 points: duplicates and exact ties
+    got = U.fps_indices(torch.from_numpy(pc).cuda(), s).cpu().numpy()
+    for c in range(2):
+        want = F.fps_indices_c(pc[c], s)
+        assert np.array_equal(got[c], want), f"cloud {c}: first mismatch at {np.argmax(got[c] != want)}"
+
+
+@pytest.mark.parametrize("n,s", [(600, 600), (5000, 5000), (8192, 8192), (12000, 12000)])
+def test_fps_all_duplicates_tail(synth, n, s):
+    """Every point on a 5 x 5 x 5 grid: after <= 125 picks only duplicates of picked points are left (maximum distance 0) and the
+    reference keeps picking the lowest remaining index (utils.py:927-931) -- the kernel's bitmap tail."""
+    U = sub("utils.utils")
+    pc = np.round(synth.uniform(3000 + n, (1, n, 3), -1.0, 1.0) * 2) / 2
+    got = U.fps_indices(torch.from_numpy(pc).cuda(), s).cpu().numpy()[0]
+    assert np.array_equal(got, F.fps_indices_c(pc[0], s))
+    assert len(np.unique(got)) == s
+
+
+def test_fps_round_stamps_diagnostic(synth):
+    """The diagnostic build returns the same indices and four increasing time stamps per round."""
+    import ctypes
+    L = sub("_lib")
+    pc = synth.clouds(77, 1, 8192)
+    xyz = torch.from_numpy(pc).cuda()
+    S = 512
+    idx = torch.empty(S, dtype=torch.int32, device="cuda")
+    stamps = torch.zeros(4 * S, dtype=torch.int64, device="cuda")
+    rc = L.lib().ampnet_fps_round_stamps(L.ptr(xyz), 8192, 3, S, L.ptr(idx), L.ptr(stamps), L.stream_ptr(xyz.device))
+    L.check(rc, "ampnet_fps_round_stamps")
+    assert np.array_equal(idx.cpu().numpy(), F.fps_indices_c(pc[0], S))
+    st = stamps.cpu().numpy().reshape(S, 4)[1:]
+    assert (np.diff(st.reshape(-1)) > 0).all()
+    d = np.median(np.diff(np.concatenate([st[:-1, 3:4], st[1:]], axis=1), axis=1), axis=0)      # update, barrier, fold, coordinates
+    print(f"fps round anatomy (cycles, median): update+wave-reduce {d[0]:.0f}, slot+barrier {d[1]:.0f}, fold {d[2]:.0f}, coordinates {d[3]:.0f}; round {d.sum():.0f}")
+
+
 def test_fps_drop_in_returns_rows(synth):
     U = sub("utils.utils")
     pc = np.concatenate([synth.clouds(5, 1, 3000)[0], synth.uniform(6, (3000, 10), 0, 1)], axis=1)

@@ -34,17 +34,53 @@ def _models(synth, params, dropout=0.3):
     return enc, att
 
 
+TIGHT = {("att", "conv_3.weight"), ("att", "conv_3.bias"), ("att", "conv_4.weight"), ("att", "conv_4.bias"), ("att", "bn_3.weight"), ("att", "bn_3.bias")}
+
+
 def _grad_rtol(tag, key):
-    """Relative bar of one gradient tensor against the reference's own fp32 gradient (tests/golden/step.npz).
-    Tensors whose gradient does not travel back through a T-Net FC BatchNorm (the head, and the encoder layers after the
-    feature transform) are well conditioned: 1e-3.  Everything upstream of bn_4 / bn_5 of a T-Net (they normalise over only
-    B = 16 rows of near-identical pooled features) carries the fp32 noise of the reference itself, up to 2e-2 from a
-    float64 evaluation (tests/test_oracle_golden.py): 3e-2."""
-    if tag == "att":
-        return 1e-3
-    if key.split(".")[0] in ("conv_3", "conv_4", "conv_5", "conv_6", "bn_3", "bn_4", "bn_5", "bn_6"):
-        return 1e-3
-    return 3e-2
+    """Relative bar of one gradient tensor against the REFERENCE's own fp32 gradient (tests/golden/step.npz).
+    Measured on the MI355X (scratch/diag_step_grads.py, B = 16, N = 64, W = 3): the reference's fp32 gradients sit 1e-3 .. 5e-3
+    (bn_5.bias: 1.3e-2) from a float64 evaluation of the same graph on EVERY tensor whose value depends on a T-Net -- the encoder
+    and, through the global features, the attention and conv_2 of the head -- and so does any other fp32 evaluation (torch's own:
+    same figures).  Only the last two head layers are free of that noise: there the HIP gradients agree with the reference to
+    1e-4 .. 1e-6 where the golden file stores them in full (torch's fp32 evaluation of conv_3.weight is itself 8e-4 from float64).
+    Hence 2e-3 for those and 1.5e-2 (observed worst 8.7e-3) for the rest; the float64-arbitrated check of _check_against_f64
+    below is the sharper statement (1e-4 on the well-conditioned tensors, noise-scaled on the others)."""
+    return 2e-3 if (tag, key) in TIGHT else 1.5e-2
+
+
+def _check_against_f64(synth, params, g, pc, tg, cent, seed, got):
+    """Arbiter = the oracle in float64 on the batch train_loop saw (the augmentation replayed from the same numpy seed).
+    A HIP gradient may be no further from float64 than 3x the distance of the better-known fp32 evaluations of the same graph
+    (the reference's own gradient from the golden file where it is stored in full, torch-CPU fp32 of the oracle otherwise)
+    + 2e-4 of its norm (observed ratio <= 1.85); the well-conditioned tensors (TIGHT) within 1e-4 outright (observed 1e-5)."""
+    from oracle import ampnet_oracle as O
+    from helpers import replay_augment, torch_params
+    apc, atg = replay_augment(seed, pc, tg, True)
+    want = {}
+    for dt in (torch.float64, torch.float32):
+        d = lambda dd, gr: {k: v.to(dt).requires_grad_(gr) for k, v in torch_params(dd).items()}      # noqa: E731
+        ep, eb = d(synth.make_params(3, params.ENC_PARAMS), True), d(synth.make_buffers(3, params.ENC_BUFFERS), False)
+        hp, hb = d(synth.make_params(4, params.HEAD_PARAMS), True), d(synth.make_buffers(4, params.HEAD_BUFFERS), False)
+        lg, tpc, tf, _ = O.forward_windows(ep, eb, hp, hb, torch.from_numpy(apc).to(dt), torch.from_numpy(atg),
+                                           torch.from_numpy(cent).to(dt), True, True)
+        c, r = O.loss_terms(lg, tpc, tf)
+        (c + 0.001 * r).backward()
+        want[dt] = {("enc", k): v.grad.double() for k, v in ep.items()}
+        want[dt].update({("att", k): v.grad.double() for k, v in hp.items()})
+    gtot = float(np.sqrt(sum(float(w.pow(2).sum()) for w in want[torch.float64].values())))
+    bad = []
+    for key, w in want[torch.float64].items():
+        nrm = float(w.norm())
+        err = float((got[key].reshape(w.shape) - w).norm())
+        noise = float((want[torch.float32][key] - w).norm())
+        gk = f"s1_{key[0]}_grad/{key[1]}"
+        if gk in g.files:
+            noise = max(noise, float((torch.from_numpy(g[gk].astype(np.float64)).reshape(w.shape) - w).norm()))
+        tol = (1e-4 * nrm if key in TIGHT else 3.0 * noise + 2e-4 * nrm) + 1e-5 * gtot
+        if not err <= tol:
+            bad.append((key, err / (nrm + 1e-30), noise / (nrm + 1e-30)))
+    assert not bad, "; ".join(f"{k}: rel err {e:.2e} (fp32 noise {n:.2e})" for k, e, n in bad[:8])
 
 
 def _batch(golden, synth):
@@ -129,6 +165,8 @@ def test_train_loop_two_steps_match_reference(golden, synth, params):
                     if key in g.files:
                         err = np.linalg.norm(got.cpu().numpy() - g[key].astype(np.float64))
                         assert err <= rt_g * gn[0] + 1e-5 * gtot, (k, err, gn[0])
+            hip = {(tag, k): p.grad.double().cpu() for tag, mod in (("enc", enc), ("att", att)) for k, p in mod.named_parameters()}
+            _check_against_f64(synth, params, g, data[0].numpy(), data[1].numpy(), data[3].numpy(), 1000 + step, hip)
         for tag, mod in (("enc", enc), ("att", att)):
             for k, p in mod.named_parameters():
                 ps = g[f"s{step}_{tag}_psum/{k}"]
