@@ -13,6 +13,7 @@ int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st);
 struct PwInputWgrad {
     const float *x = nullptr;                 // [rows, 9]
     const float *dy = nullptr, *z = nullptr;  // [rows, 64]
+    int z_bf16 = 0;                           // z is a bf16 tensor (precision mode 3)
     const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, 64]
     float *dWeff = nullptr;                   // [Q, 64, 9]
     const int *win_off = nullptr;

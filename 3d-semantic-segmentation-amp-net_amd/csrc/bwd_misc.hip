@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
                 const int i = min(i0 + 4 * u, n - 1);
                 const size_t o = (size_t)(base + i) * 64 + lane;
                 dyv[u] = a.dy[o];
-                zv[u] = a.z[o];
+                zv[u] = ld_act(a.z, o, a.z_bf16);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(512) void sparse_scatter_kernel(SparseScatter a)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 wv8[u] = a.W[(size_t)ch[u] * a.cp + k];
-                zv[u] = a.z_prev[(size_t)rowv[u] * a.cp + k];
+                zv[u] = ld_act(a.z_prev, (size_t)rowv[u] * a.cp + k, a.z_bf16);
                 ov[u] = a.out[(size_t)rowv[u] * a.cp + k];
             }
 #pragma unroll
@@ -938,9 +938,14 @@ int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int
     return check_launch("slot_mats_kernel");
 }
 
-__global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ part, int Q, int chunks, int n_slots, int n_el,
-                                                          float *__restrict__ out)
+// blockIdx.z picks one of two (partials, output) pairs: the Gram matrix and the column sums of a pooled layer share a launch
+__global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restrict__ part0, int n_el0, float *__restrict__ out0,
+                                                          const float *__restrict__ part1, int n_el1, float *__restrict__ out1, int Q, int chunks,
+                                                          int n_slots)
 {
+    const float *__restrict__ part = blockIdx.z ? part1 : part0;
+    float *__restrict__ out = blockIdx.z ? out1 : out0;
+    const int n_el = blockIdx.z ? n_el1 : n_el0;
     const int s = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_el) return;
     float a0 = 0.f, a1 = 0.f;
@@ -954,7 +959,14 @@ __global__ __launch_bounds__(256) void reduce_slots_kernel(const float *__restri
 
 int reduce_slots(const float *part, int Q, int chunks, int n_slots, int n_el, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(reduce_slots_kernel, dim3(cdiv(n_el, 256), n_slots), dim3(256), 0, st, part, Q, chunks, n_slots, n_el, out);
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(cdiv(n_el, 256), n_slots, 1), dim3(256), 0, st, part, n_el, out, part, n_el, out, Q, chunks, n_slots);
+    return check_launch("reduce_slots_kernel");
+}
+
+int reduce_slots2(const float *part0, int n_el0, float *out0, const float *part1, int n_el1, float *out1, int Q, int chunks, int n_slots, hipStream_t st)
+{
+    const int m = n_el0 > n_el1 ? n_el0 : n_el1;
+    hipLaunchKernelGGL(reduce_slots_kernel, dim3(cdiv(m, 256), n_slots, 2), dim3(256), 0, st, part0, n_el0, out0, part1, n_el1, out1, Q, chunks, n_slots);
     return check_launch("reduce_slots_kernel");
 }
 
@@ -999,7 +1011,7 @@ __global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a
 #pragma unroll 8
         for (int q = grp; q < a.Q; q += PWG_G) {
             const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
-            const float av = fmaxf(fmaf(zp[(size_t)sRow[q] * a.cp + k], sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
+            const float av = fmaxf(fmaf(ld_act(zp, (size_t)sRow[q] * a.cp + k, a.z_bf16), sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
             acc = fmaf(sCoef[q], av, acc);
         }
     }

@@ -99,7 +99,7 @@ int matrix_precision() { return g_matrix_precision; }
 
 extern "C" int ampnet_set_matrix_precision(int mode)
 {
-    if (mode != AMPNET_PRECISION_F32 && mode != AMPNET_PRECISION_BF16 && mode != AMPNET_PRECISION_BF16_TRAIN) return ampnet::fail(AMPNET_E_ARG, "ampnet_set_matrix_precision: mode %d", mode);
+    if (mode != AMPNET_PRECISION_F32 && mode != AMPNET_PRECISION_BF16 && mode != AMPNET_PRECISION_BF16_TRAIN && mode != AMPNET_PRECISION_BF16_STORE) return ampnet::fail(AMPNET_E_ARG, "ampnet_set_matrix_precision: mode %d", mode);
     ampnet::g_matrix_precision = mode;
     return AMPNET_OK;
 }

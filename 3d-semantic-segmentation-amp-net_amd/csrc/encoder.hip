@@ -126,6 +126,7 @@ struct EncRun {
     float *const *Bf;
     const int *win_off;
     BnParamRef bnp[BN_ENC_COUNT];
+    bool zb = false;           // precision mode 3: the z tensors of the workspace are bf16
 
     void bind_bn()
     {
@@ -142,10 +143,14 @@ struct EncRun {
     }
 
     // point layer on the real windows
-    PwGemm point_layer(const float *A, int cin, const float *W, int cout, int pro_bn, float *Z, bool stats, bool pool, int pool_bn = -1) const
+    // a_is_z / z_is_z: the operand is one of the workspace's pre-BatchNorm tensors (stored as bf16 in precision mode 3), not `local`
+    PwGemm point_layer(const float *A, int cin, const float *W, int cout, int pro_bn, float *Z, bool stats, bool pool, int pool_bn = -1,
+                       bool a_is_z = true, bool z_is_z = true) const
     {
         PwGemm g;
         g.A = A; g.lda = cin; g.cin = cin;
+        g.a_bf16 = (zb && a_is_z) ? 1 : 0;
+        g.z_bf16 = (zb && z_is_z && Z) ? 1 : 0;
         g.W = W; g.ldw = cin;
         if (pro_bn >= 0) { g.pro_scale = ws.bn[pro_bn].scale; g.pro_shift = ws.bn[pro_bn].shift; }
         g.n_slots = s.train ? s.n_slots : 1;
@@ -210,7 +215,7 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
     const bool tr = e.s.train;
     if (input_k3) {
         PwInput in;
-        in.x = x_or_A; in.W = e.P[pbase + TP_CONV1]; in.mode = 0; in.Z = z1;
+        in.x = x_or_A; in.W = e.P[pbase + TP_CONV1]; in.mode = 0; in.Z = z1; in.z_bf16 = e.zb ? 1 : 0;
         if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
         in.win_off = e.win_off; in.Q = e.s.Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
         TRY(pw_input(in, e.st));
@@ -263,6 +268,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     e.Bf = buffers_host;
     e.win_off = win_off;
     e.bind_bn();
+    e.zb = z_storage_bf16();
     const bool tr = train != 0;
 
     TRY(fill_i32_ramp(e.ws.fc_off, e.s.n_slots + 1, e.s.fc_rows, e.st));
@@ -279,7 +285,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     {
         PwInput in;
         in.x = x; in.W = e.P[EP_CONV1]; in.T = e.ws.T3; in.mode = 1;
-        in.perwin_slot_major = tr ? 1 : 0; in.n_slots = e.s.n_slots; in.Z = e.ws.z_c1;
+        in.perwin_slot_major = tr ? 1 : 0; in.n_slots = e.s.n_slots; in.Z = e.ws.z_c1; in.z_bf16 = e.zb ? 1 : 0;
         if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
         in.win_off = win_off; in.Q = Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
         TRY(pw_input(in, e.st));
@@ -291,12 +297,12 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(run_tnet(e, EP_FT, BN_F1, e.ws.z_c2, BN_C2, false, e.ws.z_f1, e.ws.z_f2, e.ws.z_f3, e.ws.pool_f, e.ws.arg_f, e.ws.zext_f, e.ws.z_ff1, e.ws.z_ff2, feat_T, 64));
     // local = relu(bn_2(z_c2)) x T64[window]  (torch.bmm, pointnetAtt.py:96)
     {
-        PwGemm g = e.point_layer(e.ws.z_c2, 64, feat_T, 64, BN_C2, local, false, false);
+        PwGemm g = e.point_layer(e.ws.z_c2, 64, feat_T, 64, BN_C2, local, false, false, -1, true, false);     // local leaves as fp32
         g.w_win_stride = 64 * 64;
         g.perwin_slot_major = tr ? 1 : 0;
         TRY(pw_gemm(g, e.st));
     }
-    TRY(pw_gemm(e.point_layer(local, 64, e.P[EP_CONV3], 64, -1, e.ws.z_c3, tr, false), e.st));
+    TRY(pw_gemm(e.point_layer(local, 64, e.P[EP_CONV3], 64, -1, e.ws.z_c3, tr, false, -1, false, true), e.st));
     TRY(e.finalize(BN_C3, false));
     TRY(pw_gemm(e.point_layer(e.ws.z_c3, 64, e.P[EP_CONV4], 128, BN_C3, e.ws.z_c4, tr, false), e.st));
     TRY(e.finalize(BN_C4, false));

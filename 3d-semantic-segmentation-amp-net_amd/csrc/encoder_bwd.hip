@@ -108,11 +108,26 @@ struct EncBwd {
     const int *win_off;
     const float *gamma[BN_ENC_COUNT];
     bool fused = true;         // AMPNET_FUSED_BWD=0 falls back to the separate pw_wgrad / pw_dgrad launches
+    bool zb = false;           // precision mode 3: the forward workspace holds its z tensors as bf16
+    // weight-gradient partials of the fused layers stay in wpart (one region per layer) and are reduced by ONE launch at the end
+    mutable size_t wpart_used = 0;
+    size_t wpart_cap = 0;
+    mutable ReduceItem deferred[REDUCE_MULTI_MAX];
+    mutable int n_deferred = 0;
+    int flush_deferred() const
+    {
+        if (n_deferred == 0) return AMPNET_OK;
+        const int n = n_deferred;
+        n_deferred = 0;
+        wpart_used = 0;
+        return reduce_windows_multi(deferred, n, st);
+    }
 
     GradSrc dense(const float *dy, const float *z, int bn, int C) const
     {
         GradSrc g;
         g.dy = dy; g.z = z; g.C = C;
+        g.z_bf16 = (zb && bn >= 0) ? 1 : 0;            // every BatchNorm'ed z of the workspace (the bmm path passes bn < 0 and fp32 tensors)
         if (bn >= 0) { g.P1 = b.bn[bn].P1; g.P2 = b.bn[bn].P2; g.P3 = b.bn[bn].P3; }
         return g;
     }
@@ -127,6 +142,7 @@ struct EncBwd {
     {
         ActSrc a;
         a.z = z; a.C = C;
+        a.z_bf16 = (zb && bn >= 0) ? 1 : 0;
         if (bn >= 0) { a.s = f.bn[bn].scale; a.t = f.bn[bn].shift; }
         return a;
     }
@@ -171,6 +187,7 @@ struct EncBwd {
             ActSrc y;
             if (prev_bn >= 0) y = act(prev_z, prev_bn, cy);
             else { y.z = prev_z; y.C = cy; }
+            TRY(flush_deferred());            // wgrad() reuses wpart from its start
             TRY(wgrad(g, y, dW));
             return dgrad(g, W, cy, prev_bn >= 0 ? prev_z : nullptr, prev_bn, cy, add, out);
         }
@@ -183,12 +200,22 @@ struct EncBwd {
         } else {
             p.prev.z = prev_z; p.prev.C = cy;
         }
-        p.W = W; p.ldw = cy; p.add = add; p.out = out; p.dWpart = b.wpart;
+        p.W = W; p.ldw = cy; p.add = add; p.out = out;
         p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
         p.blocks_per_slot = pw_bwd_blocks(s.Q, s.n_slots, s.max_rows);
         const int nblk = p.blocks_per_slot * s.n_slots;
+        const size_t need = align_up((size_t)nblk * g.C * cy, 64);
+        const bool defer = n_deferred < REDUCE_MULTI_MAX && wpart_used + need <= wpart_cap;
+        float *part = b.wpart + (defer ? wpart_used : 0);
+        if (!defer) TRY(flush_deferred());                       // the region at offset 0 is about to be overwritten
+        p.dWpart = part;
         TRY(pw_bwd_fused(p, st));
-        TRY(reduce_windows(b.wpart, nblk, (long)g.C * cy, g.C, cy, cy, dW, cy, 0, st));
+        if (defer) {
+            deferred[n_deferred++] = ReduceItem{part, nblk, (long)g.C * cy, g.C, cy, cy, dW, cy};
+            wpart_used += need;
+        } else {
+            TRY(reduce_windows(part, nblk, (long)g.C * cy, g.C, cy, cy, dW, cy, 0, st));
+        }
         if (prev_bn >= 0) TRY(finalize_prev(prev_bn, cy, nblk, 1));
         return AMPNET_OK;
     }
@@ -225,7 +252,7 @@ struct EncBwd {
         PooledWgrad pw;
         pw.W = W; pw.P1 = b.bn[bn].P1; pw.P2 = b.bn[bn].P2; pw.P3 = b.bn[bn].P3; pw.gram = b.gram; pw.asum = b.asum;
         pw.arg = arg; pw.dpm = b.dpm; pw.slot_major = slot_major;
-        pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift;
+        pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift; pw.z_bf16 = zb ? 1 : 0;
         pw.Q = s.Q; pw.n_slots = s.n_slots; pw.dW = dW;
         SparseFix sf;
         sf.srows = b.srows; sf.srow_row = b.srow_row; sf.srow_cnt = b.srow_cnt; sf.z_prev = z_prev;
@@ -235,22 +262,23 @@ struct EncBwd {
             // one pass over z_prev: per-slot Gram matrix + column sums of a = relu(bn_prev(z_prev)) AND
             // dy_prev = (a G[slot] + c0[slot]) masked by the previous layer's ReLU, with its BatchNorm-backward sums
             PwBwd p;
-            p.g.z = z_prev; p.g.C = 128; p.g.act = 1; p.g.P2 = f.bn[prev_bn].scale; p.g.P3 = f.bn[prev_bn].shift;
+            p.g.z = z_prev; p.g.C = 128; p.g.act = 1; p.g.P2 = f.bn[prev_bn].scale; p.g.P3 = f.bn[prev_bn].shift; p.g.z_bf16 = zb ? 1 : 0;
             p.prev = act(z_prev, prev_bn, 128);
             p.prev_mean = f.bn[prev_bn].mean; p.prev_invstd = f.bn[prev_bn].invstd;
             p.W = b.Gm; p.ldw = 128; p.w_slot_stride = 128 * 128; p.bias_slot = b.c0;
-            p.out = dy_out; p.dWpart = b.wpart; p.dbpart = b.dbpart; p.part_a = f.part_sum; p.part_b = f.part_sq;
-            p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
             p.blocks_per_slot = pw_bwd_blocks(s.Q, s.n_slots, s.max_rows);
             const int nblk = p.blocks_per_slot * s.n_slots;
+            if (wpart_used + (size_t)nblk * 128 * 128 > wpart_cap) TRY(flush_deferred());       // the Gram partials go behind the deferred regions
+            float *gpart = b.wpart + wpart_used;
+            p.out = dy_out; p.dWpart = gpart; p.dbpart = b.dbpart; p.part_a = f.part_sum; p.part_b = f.part_sq;
+            p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
             TRY(pw_bwd_fused(p, st));
-            TRY(reduce_slots(b.wpart, nblk, 1, s.n_slots, 128 * 128, b.gram, st));
-            TRY(reduce_slots(b.dbpart, nblk, 1, s.n_slots, 128, b.asum, st));
+            TRY(reduce_slots2(gpart, 128 * 128, b.gram, b.dbpart, 128, b.asum, nblk, 1, s.n_slots, st));
             TRY(pooled_wgrad(pw, st));
             // the scattered rows: added after the dense part, their share of the sums goes behind the workgroup partials
             SparseScatter ss;
             ss.arg = arg; ss.dpm = b.dpm; ss.slot_major = slot_major; ss.P1 = b.bn[bn].P1; ss.W = W;
-            ss.z_prev = z_prev; ss.s_prev = f.bn[prev_bn].scale; ss.t_prev = f.bn[prev_bn].shift;
+            ss.z_prev = z_prev; ss.s_prev = f.bn[prev_bn].scale; ss.t_prev = f.bn[prev_bn].shift; ss.z_bf16 = zb ? 1 : 0;
             ss.mean_prev = f.bn[prev_bn].mean; ss.invstd_prev = f.bn[prev_bn].invstd;
             ss.Q = s.Q; ss.n_slots = s.n_slots; ss.out = dy_out;
             ss.part_a = f.part_sum + (size_t)nblk * 128; ss.part_b = f.part_sq + (size_t)nblk * 128;
@@ -344,6 +372,9 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         const char *env = getenv("AMPNET_FUSED_BWD");
         e.fused = !(env && env[0] == '0');
     }
+    e.zb = z_storage_bf16();
+    AMPNET_REQUIRE(!e.zb || e.fused, "ampnet_encoder_bwd_f32: bf16 activation storage needs the fused backward");
+    e.wpart_cap = e.fused ? ((size_t)Q * (size_t)wg_chunks(e.s) + 320 + n_slots) * 256 * 128 : 0;      // floats in b.wpart (enc_bwd_carve)
     const float *const *P = params_host;
     float *const *G = grads_host;
     for (int i = 0; i < 5; ++i) {
@@ -443,7 +474,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     {
         PwInputWgrad w;
-        w.x = x; w.dy = b.dyB; w.z = f.z_c1;
+        w.x = x; w.dy = b.dyB; w.z = f.z_c1; w.z_bf16 = e.zb ? 1 : 0;
         w.P1 = b.bn[BN_C1].P1; w.P2 = b.bn[BN_C1].P2; w.P3 = b.bn[BN_C1].P3;
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));
@@ -458,12 +489,13 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     {
         PwInputWgrad w;
-        w.x = x; w.dy = b.dyB; w.z = f.z_t1;
+        w.x = x; w.dy = b.dyB; w.z = f.z_t1; w.z_bf16 = e.zb ? 1 : 0;
         w.P1 = b.bn[BN_T1].P1; w.P2 = b.bn[BN_T1].P2; w.P3 = b.bn[BN_T1].P3;
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));
         TRY(input_param_grads(b.dWeff, P[EP_IT + TP_CONV1], nullptr, Q, n_slots, 0, 0, G[EP_IT + TP_CONV1], nullptr, st));
     }
+    TRY(e.flush_deferred());           // every fused layer's weight gradient: one reduction launch
     // ---- BatchNorm weight / bias gradients: sums over the slots of (sum dy, sum dy * zhat) -----------------------------
     {
         const int ids[16] = {BN_T1, BN_T2, BN_T3, BN_T4, BN_T5, BN_F1, BN_F2, BN_F3, BN_F4, BN_F5, BN_C1, BN_C2, BN_C3, BN_C4, BN_C5, BN_C6};

@@ -121,6 +121,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     const float dp = tr ? drop_p : 0.f;
     const int Q = s.Q;
 
+    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 are stored as bf16 (precision mode 3)
     TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
     auto tok_gemm = [&](const float *A, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
@@ -156,7 +157,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         g.A = lo; g.lda = 64; g.cin = 64;
         g.W = P[HP_CONV2_W]; g.ldw = 320;
         g.bias = ws.gbias; g.bias_win_stride = 128;
-        g.Z = ws.z2; g.ldz = 128; g.cout = 128;
+        g.Z = ws.z2; g.ldz = 128; g.cout = 128; g.z_bf16 = zb;
         if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
         g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
@@ -164,11 +165,11 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     }
     {   // conv_3 on dropout(relu(bn_2(z2)))
         PwGemm g;
-        g.A = ws.z2; g.lda = 128; g.cin = 128;
+        g.A = ws.z2; g.lda = 128; g.cin = 128; g.a_bf16 = zb;
         g.W = P[HP_CONV3_W]; g.ldw = 128; g.bias = P[HP_CONV3_B];
         g.pro_scale = ws.bn2.scale; g.pro_shift = ws.bn2.shift;
         g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
-        g.Z = ws.z3; g.ldz = 64; g.cout = 64;
+        g.Z = ws.z3; g.ldz = 64; g.cout = 64; g.z_bf16 = zb;
         if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
         g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
@@ -185,7 +186,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
         int blocks = 0;
         // conv_4 on the matrix cores (the 5 output columns ride in one 32-column MFMA tile), then the row-wise tail
         PwGemm g;
-        g.A = ws.z3; g.lda = 64; g.cin = 64;
+        g.A = ws.z3; g.lda = 64; g.cin = 64; g.a_bf16 = zb;
         g.W = P[HP_CONV4_W]; g.ldw = 64; g.bias = P[HP_CONV4_B];
         g.pro_scale = ws.bn3.scale; g.pro_shift = ws.bn3.shift;
         g.drop_p = dp; g.drop_seed = drop_base(seed, 2);

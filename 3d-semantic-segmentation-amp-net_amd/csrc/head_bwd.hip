@@ -16,6 +16,7 @@ constexpr int HB_WAVES = 4, HB_WROWS = 256, HB_ROWS = HB_WAVES * HB_WROWS;   // 
 struct HeadOutBwd {
     const float *dlogits;      // [B, C, P]
     const float *z3;           // [R, 64]
+    int z_bf16;                // z3 is a bf16 tensor (precision mode 3)
     const float *scale, *shift, *mean, *invstd;   // bn_3 [64]
     const float *W;            // [C, 64]
     float drop_p;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd 
         // the next eight rows are requested before the current eight are processed (register double buffer)
         float zn[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) zn[u] = a.z3[(size_t)min(r0 + u, a.R - 1) * 64 + k];
+        for (int u = 0; u < 8; ++u) zn[u] = ld_act(a.z3, (size_t)min(r0 + u, a.R - 1) * 64 + k, a.z_bf16);
 #pragma unroll 1
         for (int i0 = 0; i0 < 64; i0 += 8) {
             if (r0 + i0 >= a.R) break;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd 
             for (int u = 0; u < 8; ++u) zv[u] = zn[u];
             if (i0 + 8 < 64) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) zn[u] = a.z3[(size_t)min(r0 + i0 + 8 + u, a.R - 1) * 64 + k];
+                for (int u = 0; u < 8; ++u) zn[u] = ld_act(a.z3, (size_t)min(r0 + i0 + 8 + u, a.R - 1) * 64 + k, a.z_bf16);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -303,11 +304,12 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     const int blocks = cdiv(R, HB_ROWS);
     const int wch = cdiv(max_rows, 1024);
 
+    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 of this forward workspace are bf16 tensors (precision mode 3)
     TRY(fill_i32_ramp(b.tot_off, 2, R, st));
     // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
     {
         HeadOutBwd o;
-        o.dlogits = dlogits; o.z3 = f.z3;
+        o.dlogits = dlogits; o.z3 = f.z3; o.z_bf16 = zb;
         o.scale = f.bn3.scale; o.shift = f.bn3.shift; o.mean = f.bn3.mean; o.invstd = f.bn3.invstd;
         o.W = P[HP_CONV4_W]; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
         o.R = R; o.P = R / B; o.C = C;
@@ -325,11 +327,12 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     }
     // ---- conv_3: z3 = dropout(relu(bn_2(z2))) W3^T + b3 --------------------------------------------------
     GradSrc g3;
-    g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1];
+    g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1]; g3.z_bf16 = zb;
     ActSrc a2;
-    a2.z = f.z2; a2.C = 128; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
+    a2.z = f.z2; a2.C = 128; a2.z_bf16 = zb; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
     const char *fenv = getenv("AMPNET_FUSED_BWD");
     const bool fused = !(fenv && fenv[0] == '0');
+    AMPNET_REQUIRE(!zb || fused, "ampnet_head_bwd_f32: bf16 activation storage needs the fused backward");
     if (fused) {
         // one pass over (dy3, z3, z2): weight + bias gradient partials and dy2 with bn_2's backward sums
         PwBwd p;
@@ -369,13 +372,14 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     }
     // ---- conv_2: z2 = lo W2[:, :64]^T + (token W2[:, 64:]^T + b2)[window] ------------------------------------
     GradSrc g2;
-    g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0];
+    g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0]; g2.z_bf16 = zb;
     // fused form: every workgroup stays inside one window, so its column sums of g2 are a per-window partial of the
     // token-bias gradient
     const int cpw = cdiv(max_rows, pw_bwd_item_rows());
     int ipb = cpw < 4 ? cpw : 4;
     while (cpw % ipb) --ipb;
     const int bpw = cpw / ipb;                                  // workgroups per window
+    AMPNET_REQUIRE(!zb || bpw <= wch, "ampnet_head_bwd_f32: bf16 activation storage needs the fused conv_2 backward");
     if (fused && bpw <= wch) {
         PwBwd p;
         p.g = g2; p.prev.z = lo; p.prev.C = 64;

@@ -42,8 +42,18 @@ struct PwGemm {
     int chunk_rows = 512;
     int chunks = 1;                // cdiv(max window rows, chunk_rows)
     long rows_hint = 0;            // total rows (profiling only: algorithmic flops / bytes of the launch)
+    int a_bf16 = 0, z_bf16 = 0;    // A / Z are bf16 tensors ([rows, lda] / [rows, ldz] ELEMENTS): activation storage of precision mode 3
 };
 int pw_gemm(const PwGemm &a, hipStream_t st);
+// one element of an activation tensor that is fp32 or (precision mode 3) bf16
+__device__ __forceinline__ float ld_act(const float *base, size_t elem, int bf16)
+{
+    return bf16 ? (float)reinterpret_cast<const __bf16 *>(base)[elem] : base[elem];
+}
+// activations kept for the backward (the nine pre-BatchNorm z tensors of the encoder, z2 / z3 of the head) are stored as bf16
+inline bool z_storage_bf16() { return matrix_precision() == AMPNET_PRECISION_BF16_STORE; }
+// bf16 MFMA operands in the fused backward (modes 2 and 3)
+inline bool bwd_operands_bf16() { return matrix_precision() >= AMPNET_PRECISION_BF16_TRAIN; }
 
 // First layers with a tiny contraction (K = 3 or 12), VALU: Z[row, 0:64] = x[row, cols] * Weff^T
 //   mode 0: Weff = W[64][3] on x[:, 0:3]                                     (T-Net conv_1 on xyz)
@@ -57,6 +67,7 @@ struct PwInput {
     int perwin_slot_major = 0;
     int n_slots = 1;
     float *Z = nullptr;            // [rows, 64]
+    int z_bf16 = 0;                // Z is a bf16 tensor (precision mode 3)
     float *part_sum = nullptr, *part_sq = nullptr;    // [Q * chunks, 64] or nullptr (chunk mean, chunk M2)
     const int *win_off = nullptr;
     int Q = 0, chunk_rows = 512, chunks = 1;
@@ -154,6 +165,7 @@ struct GradSrc {
     const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, C]
     int act = 0;                   // 1: g = relu(z * P2 + P3) -- a recomputed forward activation used as the operand
     int C = 0;
+    int z_bf16 = 0;                // z is a bf16 tensor (activation storage of precision mode 3; fused bf16 kernels only)
 };
 
 // How the forward activation a_{l-1} [rows, C] is recomputed: relu(z * s + t) (+ dropout), or z itself
@@ -163,6 +175,7 @@ struct ActSrc {
     float drop_p = 0.f;
     uint32_t drop_seed = 0;
     int C = 0;
+    int z_bf16 = 0;                // z is a bf16 tensor (precision mode 3)
 };
 
 // data gradient: out[row, j] = sum_k g[row, k] * W[k, j]  (+ add[row, j]), then optionally the ReLU/dropout mask
@@ -242,6 +255,17 @@ int pw_bwd_fused_bf16(const PwBwd &a, hipStream_t st);     // the same pass with
 // element i = (r, c) with c < cols -> dst[r * ld_dst + c]
 int reduce_windows(const float *part, int Q, long stride, int rows, int cols, int ld_part, float *dst, int ld_dst, int accumulate,
                    hipStream_t st);
+// the same reduction (overwrite form) for up to REDUCE_MULTI_MAX (partials, destination) pairs in ONE launch
+constexpr int REDUCE_MULTI_MAX = 12;
+struct ReduceItem {
+    const float *part;
+    int Q;
+    long stride;
+    int rows, cols, ld_part;
+    float *dst;
+    int ld_dst;
+};
+int reduce_windows_multi(const ReduceItem *items, int n, hipStream_t st);
 
 // BatchNorm backward constants of one layer from the partial sums of pw_dgrad / head_out_bwd / pool_bwd:
 //   per slot: A = sum dy, Bs = sum dy * zhat  ->  P1 = s, P2 = -s * invstd * Bs / n, P3 = -s * A / n - P2 * mean,
@@ -309,6 +333,7 @@ struct SparseFix {
 int sparse_fix(const SparseFix &a, hipStream_t st);
 // sparse_rows + sparse_fix in one kernel, no [Q * C, cp] intermediate (the fused backward uses this one)
 struct SparseScatter {
+    int z_bf16 = 0;                     // z_prev is a bf16 tensor (precision mode 3)
     const int *arg = nullptr;           // [Q, C]
     const float *dpm = nullptr;         // [Q, C]
     int slot_major = 0;
@@ -324,7 +349,10 @@ int sparse_scatter(const SparseScatter &a, hipStream_t st);
 int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st);
 // out[s][e] = sum over windows q = s (mod n_slots), chunks: part[(q * chunks + ch) * n_el + e]
 int reduce_slots(const float *part, int Q, int chunks, int n_slots, int n_el, float *out, hipStream_t st);
+// two such reductions over the same (Q, chunks, n_slots) in one launch
+int reduce_slots2(const float *part0, int n_el0, float *out0, const float *part1, int n_el1, float *out1, int Q, int chunks, int n_slots, hipStream_t st);
 struct PooledWgrad {
+    int z_bf16 = 0;                     // z_prev is a bf16 tensor (precision mode 3)
     const float *W = nullptr, *P2 = nullptr, *P3 = nullptr, *gram = nullptr, *asum = nullptr;   // [C,cp] [S,C] [S,C] [S,cp,cp] [S,cp]
     const int *arg = nullptr;           // [Q, C]
     const float *dpm = nullptr, *P1 = nullptr;

@@ -562,6 +562,63 @@ __global__ __launch_bounds__(256) void reduce_windows_kernel(const float *__rest
     }
 }
 
+// several reductions in one launch (the weight-gradient partials of the fused layer backward, deferred to the end of a backward pass)
+struct ReduceMultiArgs {
+    ReduceItem it[REDUCE_MULTI_MAX];
+    int first_block[REDUCE_MULTI_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void reduce_windows_multi_kernel(ReduceMultiArgs a)
+{
+    __shared__ float red[8][32];
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
+    const ReduceItem it = a.it[k];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = ((int)blockIdx.x - a.first_block[k]) * 32 + el;
+    const bool ok = i < it.rows * it.cols;
+    const int rr = ok ? i / it.cols : 0, c = ok ? i % it.cols : 0;
+    const float *p = it.part + (size_t)rr * it.ld_part + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+        int qi = g;
+        for (; qi + 56 < it.Q; qi += 64) {             // 8 independent loads per trip, the order of reduce_windows_kernel
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(qi + 8 * u) * it.stride];
+            s0 += (v[0] + v[2]) + (v[4] + v[6]);
+            s1 += (v[1] + v[3]) + (v[5] + v[7]);
+        }
+        for (; qi < it.Q; qi += 8) s0 += p[(size_t)qi * it.stride];
+    }
+    red[g][el] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += red[j][el];
+        it.dst[(size_t)rr * it.ld_dst + c] = s;
+    }
+}
+
+int reduce_windows_multi(const ReduceItem *items, int n, hipStream_t st)
+{
+    AMPNET_REQUIRE(n >= 1 && n <= REDUCE_MULTI_MAX, "reduce_windows_multi: %d items", n);
+    ReduceMultiArgs a;
+    a.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        AMPNET_REQUIRE(items[i].part && items[i].dst && items[i].Q >= 1 && items[i].rows >= 1 && items[i].cols >= 1, "reduce_windows_multi: bad item %d", i);
+        a.it[i] = items[i];
+        a.first_block[i] = blocks;
+        blocks += cdiv(items[i].rows * items[i].cols, 32);
+    }
+    a.first_block[n] = blocks;
+    hipLaunchKernelGGL(reduce_windows_multi_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return check_launch("reduce_windows_multi_kernel");
+}
+
 int reduce_windows(const float *part, int Q, long stride, int rows, int cols, int ld_part, float *dst, int ld_dst, int accumulate,
                    hipStream_t st)
 {

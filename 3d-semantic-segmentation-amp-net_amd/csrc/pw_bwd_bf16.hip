@@ -45,16 +45,13 @@ __device__ __forceinline__ bf16x8 tr_operand(const __bf16 *tile, int ld, int row
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * ld));
-    bf16x8 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o[i] = __builtin_bit_cast(__bf16, lo[i]);
-        o[4 + i] = __builtin_bit_cast(__bf16, hi[i]);
-    }
-    return o;
+    // whole-vector bit casts + one shuffle: an element-by-element short -> __bf16 copy is miscompiled by this hipcc (ROCm 7.2: it keeps
+    // only the first dword of each read; scratch/tr_probe.hip checks the operand map on the hardware)
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP = false>
+// ZG / ZP: g.z / prev.z are bf16 tensors (activation storage of precision mode 3) -- compile-time, like every other mode of this kernel
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP, bool ZG, bool ZP>
 __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
 {
     constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 elements per row of the operand tiles (2 C + 64 bytes)
@@ -145,6 +142,15 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
         return open_item(p.item + 1, p);
     };
 
+    // the z tensors may be stored as bf16 (precision mode 3): 8-byte loads, widened on arrival; everything downstream is unchanged
+    constexpr bool zg_bf = ZG, zp_bf = ZP;
+    auto load_z4 = [](const float *base, size_t elem, bool bf) -> f32x4 {
+        if (bf) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(base) + elem);
+            return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+        return *reinterpret_cast<const f32x4 *>(base + elem);
+    };
     f32x4 rx_dy[NIX], rx_z[NIX], ry_z[NIY];
     auto load_regs = [&](const Pos &p) {
 #pragma unroll
@@ -152,14 +158,14 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
             const int row = p.row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
             if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            rx_z[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+            rx_z[i] = load_z4(a.g.z, rr * CX + 4 * cqx, zg_bf);
         }
         if (!GRAM) {
 #pragma unroll
             for (int i = 0; i < NIY; ++i) {
                 const int row = p.row0 + rsy + SY * i;
                 const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-                ry_z[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
+                ry_z[i] = load_z4(a.prev.z, rr * CY + 4 * cqy, zp_bf);
             }
         }
     };
@@ -361,8 +367,8 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
     }
 }
 
-template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP = false>
-static int launch_bf16_x(const PwBwd &a, hipStream_t st)
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP, bool ZG, bool ZP>
+static int launch_bf16_z(const PwBwd &a, hipStream_t st)
 {
     constexpr int SX = 256 / (CX / 4);
     constexpr size_t red_floats = (size_t)(CX * SX > 8 * CY ? CX * SX : 8 * CY);
@@ -370,7 +376,7 @@ static int launch_bf16_x(const PwBwd &a, hipStream_t st)
                            (size_t)CY * (CX + 8) * 2 + red_floats * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    auto kern = pw_bwd_bf16_kernel<CX, CY, ROWS, GRAM, YACT, ADD, DROP>;
+    auto kern = pw_bwd_bf16_kernel<CX, CY, ROWS, GRAM, YACT, ADD, DROP, ZG, ZP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_bf16: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -380,9 +386,25 @@ static int launch_bf16_x(const PwBwd &a, hipStream_t st)
     snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s bf16", CX, CY, a.g.act ? "+gram" : "");
     const double rows = (double)a.rows_hint;
     const bool same = a.g.act && a.g.z == a.prev.z;
-    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * ((a.g.dy ? CX : 0) + ((a.g.P1 || a.g.act) ? CX : 0) + (same ? 0 : CY) + CY + (a.add ? CY : 0)), st);
+    const double zgb = a.g.z_bf16 ? 2.0 : 4.0, zpb = a.prev.z_bf16 ? 2.0 : 4.0;
+    ProfScope prof(name, 4.0 * rows * CX * CY, rows * ((a.g.dy ? 4.0 * CX : 0.0) + ((a.g.P1 || a.g.act) ? zgb * CX : 0.0) + (same ? 0.0 : zpb * CY) + 4.0 * CY + (a.add ? 4.0 * CY : 0.0)), st);
     hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(FBB_THREADS), lds, st, a);
     return check_launch("pw_bwd_bf16_kernel");
+}
+
+// storage formats of the two z tensors: both fp32 (modes 1 / 2), both bf16, or one of them an fp32 tensor that crosses the ABI
+// (`local` as a layer input: ZP = false; the bmm backward's d_local as "z": ZG = false)
+template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP = false>
+static int launch_bf16_x(const PwBwd &a, hipStream_t st)
+{
+    const bool zg = a.g.z_bf16 != 0, zp = a.prev.z_bf16 != 0;
+    if (!zg && !zp) return launch_bf16_z<CX, CY, ROWS, GRAM, YACT, ADD, DROP, false, false>(a, st);
+    if (zg && zp) return launch_bf16_z<CX, CY, ROWS, GRAM, YACT, ADD, DROP, true, true>(a, st);
+    if constexpr (!GRAM && !DROP) {
+        if (zg) return launch_bf16_z<CX, CY, ROWS, GRAM, YACT, ADD, DROP, true, false>(a, st);
+        if constexpr (CX == 64 && CY == 64 && YACT && !ADD) return launch_bf16_z<CX, CY, ROWS, GRAM, YACT, ADD, DROP, false, true>(a, st);
+    }
+    return fail(AMPNET_E_ARG, "pw_bwd_bf16<%d,%d>: storage combination (g.z bf16 = %d, prev.z bf16 = %d) not built", CX, CY, (int)zg, (int)zp);
 }
 
 template <int CX, int CY, int ROWS>

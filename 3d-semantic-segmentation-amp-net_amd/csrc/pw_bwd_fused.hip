@@ -481,7 +481,8 @@ int pw_bwd_fused(const PwBwd &a, hipStream_t st)
                    "pw_bwd_fused: per-window weights need workgroups that stay inside one window");
     AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
     AMPNET_REQUIRE(a.prev.C == 0 || pw_bwd_supported(a.g.C, a.prev.C), "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
-    if (matrix_precision() == AMPNET_PRECISION_BF16_TRAIN) return pw_bwd_fused_bf16(a, st);      // bf16 MFMA operands (pw_bwd_bf16.hip)
+    if (bwd_operands_bf16()) return pw_bwd_fused_bf16(a, st);
+    AMPNET_REQUIRE(!a.g.z_bf16 && !a.prev.z_bf16, "pw_bwd_fused: bf16 activation tensors need a bf16 precision mode");      // bf16 MFMA operands (pw_bwd_bf16.hip)
     if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);
     if (a.g.C == 128 && a.prev.C == 64) return launch_fused<128, 64, 64>(a, st);
     if (a.g.C == 64 && a.prev.C == 64) return launch_fused<64, 64, 64>(a, st);

@@ -51,7 +51,9 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // BF: the MFMA operands are rounded to bf16 (activations after the prologue, weights while staged) and multiplied on
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 16 x the fp32 matrix rate; HBM tensors, BatchNorm statistics, the
 // prologue and the epilogue stay fp32 (ampnet_set_matrix_precision).  Lane (r, h) then owns k = 16 s + 8 h .. + 7 of step s.
-template <int CIN, int NT, int PRO, bool POOL, bool BF>
+// ABF / ZBF (BF kernels only): A / Z are bf16 tensors (activation storage of precision mode 3); compile-time so that the K loop
+// stays one basic block (as a run-time flag the bf16 kernels ran 10-35 % slower).
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
     constexpr int CB = 32 * NT;
@@ -183,49 +185,28 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     // float offset of the j-th 16-byte piece of a 32-k block: fp32 k = 8 j + 4 h .. + 3; bf16 k = 16 (j / 2) + 8 h + 4 (j & 1) .. + 3
     auto frag_off = [](int j) -> int { return BF ? 16 * (j >> 1) + 4 * (j & 1) : 8 * j; };
 
+    // A stored as bf16 (ampnet precision mode 3, BF kernels only): the 8 consecutive k of an MFMA step are ONE 16-byte load; the raw
+    // bits ride in a_cur[2 s] / a_nxt[2 s] (the odd entries stay unused) and are widened to fp32 for the prologue
+    constexpr bool a_bf = BF && ABF;
+    auto load_frags = [&](f32x4 (&dst)[4], int t_, int kb_) {
+        if (a_bf) {
+            const int row0_ = row_begin + t_ * 32;
+            const int arow_ = row0_ + min(r, min(32, row_end - row0_) - 1);
+            const __bf16 *ap = reinterpret_cast<const __bf16 *>(a.A) + (size_t)arow_ * a.lda + 32 * kb_ + 8 * h;
+            dst[0] = *reinterpret_cast<const f32x4 *>(ap);
+            dst[2] = *reinterpret_cast<const f32x4 *>(ap + 16);
+        } else {
+            const float *ap = frag_ptr(t_, kb_);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
+        }
+    };
     int tile = wave;
-    if (tile < ntiles) {
-        const float *ap = frag_ptr(tile, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
-    }
-    // fp32 path: the operands of a k step (weights bv[t] of every column tile, prologue-transformed activations av) are read /
-    // computed ONE STEP AHEAD, under the MFMAs of the current step: the matrix pipe never waits on an LDS round trip (PMC before
-    // this: matrix pipes busy 67 % of the cycles, two exposed ds_read latencies per 16 MFMAs).  The chain runs across k blocks,
-    // tiles (the weights do not depend on the tile) and is primed once per block of rows (the prologue constants may change).
-    auto pro_apply = [&](f32x4 v, const f32x4 &sc, const f32x4 &sh, int row, int k0) -> f32x4 {
-        if (PRO) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
-            if (PRO == 2) {
-                const uint32_t e0 = (uint32_t)row * (uint32_t)CIN + (uint32_t)k0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? v[i] * dscale : 0.f;
-            }
-        }
-        return v;
-    };
-    auto arow_of = [&](int t_) -> int {
-        const int row0_ = row_begin + t_ * 32;
-        return row0_ + min(r, min(32, row_end - row0_) - 1);
-    };
-    f32x4 bv[NT], av = {0.f, 0.f, 0.f, 0.f};
-    if (!BF && tile < ntiles) {
-        const int k0 = 4 * h;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0);
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (PRO) {
-            sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
-            sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
-        }
-        av = pro_apply(a_cur[0], sc, sh, arow_of(tile), k0);
-    }
+    if (tile < ntiles) load_frags(a_cur, tile, 0);
     for (; tile < ntiles; tile += PW_NW) {
         const int row0 = row_begin + tile * 32;
         const int valid = min(32, row_end - row0);
         const int arow = row0 + min(r, valid - 1);
-        const int arow_next = (tile + PW_NW < ntiles) ? arow_of(tile + PW_NW) : arow;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -241,17 +222,21 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     ptile = tile + PW_NW;
                     pkb = 0;
                 }
-                if (ptile < ntiles) {
-                    const float *ap = frag_ptr(ptile, pkb);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a_nxt[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
-                }
+                if (ptile < ntiles) load_frags(a_nxt, ptile, pkb);
             }
             if (BF) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int k0 = 32 * kb + 16 * s2 + 8 * h;
                     f32x4 lo = a_cur[2 * s2], hi = a_cur[2 * s2 + 1];
+                    if (a_bf) {
+                        const bf16x8 raw = __builtin_bit_cast(bf16x8, a_cur[2 * s2]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lo[i] = (float)raw[i];
+                            hi[i] = (float)raw[4 + i];
+                        }
+                    }
                     if (PRO) {
                         const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sPro + k0), sc1 = *reinterpret_cast<const f32x4 *>(sPro + k0 + 4);
                         const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0), sh1 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0 + 4);
@@ -277,31 +262,28 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[t], acc[t], 0, 0, 0);
                 }
             }
-            if (!BF) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // the step after this one: (kb, j + 1), or step 0 of the next k block / of this wave's next tile
-                    const bool wrap = j == 3;
-                    const int k0n = (wrap ? (32 * (kb + 1)) % CIN : 32 * kb + 8 * (j + 1)) + 4 * h;
-                    const int row_n = (wrap && kb == NBLK - 1) ? arow_next : arow;
-                    f32x4 sc_n = {1.f, 1.f, 1.f, 1.f}, sh_n = {0.f, 0.f, 0.f, 0.f}, av_n = av;
+            for (int j = 0; j < (BF ? 0 : 4); ++j) {
+                const int k0 = 32 * kb + 8 * j + 4 * h;
+                f32x4 av = a_cur[j];
+                if (PRO) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
+                    for (int i = 0; i < 4; ++i) av[i] = fmaxf(fmaf(av[i], sc[i], sh[i]), 0.f);
+                    if (PRO == 2) {
+                        const uint32_t e0 = (uint32_t)arow * (uint32_t)CIN + (uint32_t)k0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t][i], acc[t], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);      // the four MFMAs first ...
-                        // ... then, in their shadow: tile t's weights are dead, fetch the next step's; the prologue constants are
-                        // requested two tiles before the VALU that consumes them
-                        bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0n);
-                        if (PRO && t == 0) {
-                            sc_n = *reinterpret_cast<const f32x4 *>(sPro + k0n);
-                            sh_n = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0n);
-                        }
-                        if (t == (NT > 2 ? 2 : NT - 1)) av_n = pro_apply(wrap ? a_nxt[0] : a_cur[(j + 1) & 3], sc_n, sh_n, row_n, k0n);
-                        __builtin_amdgcn_sched_barrier(0);      // keep this order: the scheduler would sink the reads to their use
+                        for (int i = 0; i < 4; ++i) av[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? av[i] * dscale : 0.f;
                     }
-                    av = av_n;
                 }
+                f32x4 bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t][i], acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
@@ -328,7 +310,10 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                     const float v = acc[t][e] + bias_v[t];
                     const bool ok = FULL || rr < valid;
-                    if (do_store && ok && cok) zp[(size_t)rr * a.ldz] = v;
+                    if (do_store && ok && cok) {
+                        if (BF && ZBF) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr) * a.ldz + col] = (__bf16)v;
+                        else zp[(size_t)rr * a.ldz] = v;
+                    }
                     if (do_stats) {
                         const float d = ok ? v - s_z0[t] : 0.f;
                         s_sum[t] += d;
@@ -414,7 +399,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
   }   // blocks of rows
 }
 
-template <int CIN, int NT, int PRO, bool POOL, bool BF>
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false>
 static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
@@ -422,7 +407,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
     constexpr size_t lds = lds_main + lds_red;
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
-    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF>;
     if (resident == 0) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -442,7 +427,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     char name[64];
     snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
     const double rows = (double)a.rows_hint;
-    ProfScope prof(name, 2.0 * rows * CIN * a.cout, rows * 4.0 * ((double)CIN * cdiv(a.cout, CB) + (a.Z ? a.cout : 0)), st);
+    ProfScope prof(name, 2.0 * rows * CIN * a.cout, rows * ((a.a_bf16 ? 2.0 : 4.0) * (double)CIN * cdiv(a.cout, CB) + (a.Z ? (a.z_bf16 ? 2.0 : 4.0) * a.cout : 0.0)), st);
     hipLaunchKernelGGL(kern, grid, dim3(PW_NW * 64), lds, st, a);
     return check_launch("pw_gemm_kernel");
 }
@@ -450,7 +435,12 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
 template <int CIN, int NT, int PRO, bool POOL>
 static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
-    return matrix_precision() != AMPNET_PRECISION_F32 ? launch_pw_y<CIN, NT, PRO, POOL, true>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+    if (matrix_precision() == AMPNET_PRECISION_F32) return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+    const bool abf = a.a_bf16 != 0, zbf = a.z_bf16 != 0 && a.Z != nullptr;
+    if (abf && zbf) return launch_pw_y<CIN, NT, PRO, POOL, true, true, true>(a, st);
+    if (abf) return launch_pw_y<CIN, NT, PRO, POOL, true, true, false>(a, st);
+    if (zbf) return launch_pw_y<CIN, NT, PRO, POOL, true, false, true>(a, st);
+    return launch_pw_y<CIN, NT, PRO, POOL, true>(a, st);
 }
 
 // the (prologue, pool) variants each shape is actually used with; anything else is an argument error
@@ -480,6 +470,8 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_gemm: part_sum/part_sq must come together");
     AMPNET_REQUIRE(!a.part_max || a.part_amax, "pw_gemm: pool partials incomplete");
+    AMPNET_REQUIRE(!(a.a_bf16 || a.z_bf16) || matrix_precision() != AMPNET_PRECISION_F32, "pw_gemm: bf16 tensors need a bf16 precision mode");
+    AMPNET_REQUIRE(!a.a_bf16 || a.lda % 8 == 0, "pw_gemm: bf16 A needs lda %% 8 == 0");
     int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);
     // tiny problems (the T-Net FC layers: nine blocks of 64 rows): narrower column blocks = more workgroups, each staging a
     // smaller weight tile -- they are bound by that staging latency, not by the matrix cores

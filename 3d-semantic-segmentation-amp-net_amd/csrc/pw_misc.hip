@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
 #pragma unroll
                 for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
             }
-            a.Z[(size_t)(base + i) * 64 + lane] = z;
+            if (a.z_bf16) reinterpret_cast<__bf16 *>(a.Z)[(size_t)(base + i) * 64 + lane] = (__bf16)z;
+            else a.Z[(size_t)(base + i) * 64 + lane] = z;
             if (cnt == 0) z0 = z;
             const float d = z - z0;
             s += d;

@@ -85,6 +85,24 @@ def pmc_traffic_for(name, rows=None):
     return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
 
 
+def pmc_counters_for(name, rows=None):
+    """(matrix-pipe busy fraction, shader clock in GHz) of the kernel bench.py calls `name`, from the rocprofv3 SQ passes summarised in
+    profiles/r02_pmc_counters.json (profiles/pmc_counters.py): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), i.e. at the
+    clock the chip actually held -- roofline.frac prices the same kernel against the 2.4 GHz peak.  None when not collected."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    cpath = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+    if not (os.path.exists(tpath) and os.path.exists(cpath)):
+        return None
+    table = json.load(open(tpath))
+    ev = table.get("events", {}).get(name)
+    if not ev or "grid" not in ev or (rows is not None and ev.get("workload_rows", table.get("workload_rows")) != rows):
+        return None
+    c = json.load(open(cpath)).get(f"{ev['symbol']}|grid={ev['grid']}")
+    if not c or "mfma_busy" not in c:
+        return None
+    return {"mfma_busy": round(c["mfma_busy"], 4), "sclk_ghz": round(c.get("sclk_ghz", 0.0), 3), "launch_us_under_pmc": round(c.get("duration_us", 0.0), 1)}
+
+
 def roofline_from(rows, work_rows=None):
     if not rows:
         return None
@@ -96,7 +114,7 @@ def roofline_from(rows, work_rows=None):
     if intensity >= peak_tf * 1e3 / PEAK_HBM_GBPS:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s",
-                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"], work_rows),
+                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"], work_rows), mfma_busy=pmc_counters_for(top["name"], work_rows),
                     algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
                     launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
@@ -317,7 +335,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational legs (train_loop_inclusive, fps)")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train", "bf16_store"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
                     help="MFMA operand precision: fp32 (headline), bf16 = forward per-point layers, bf16_train = forward + fused backward (fp32 accumulate)")
     args = ap.parse_args()
 
@@ -448,8 +466,10 @@ def main():
             dt_bf = float(tt.item())
         return {"ms_per_step": round(dt_bf / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1), "note": note}
 
-    bf16_leg = bf16_train_leg = None
+    bf16_leg = bf16_train_leg = bf16_store_leg = None
     if mode == "train" and args.precision == "fp32":
+        bf16_store_leg = precision_leg("bf16_store", "bf16_train + the activations kept for the backward (nine encoder z tensors, z2 / z3 of the head) "
+                                                     "stored as bf16; inputs, outputs, gradients, parameters, statistics f32; bar: tests/test_bf16_gpu.py")
         bf16_leg = precision_leg("bf16", "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32")
         bf16_train_leg = precision_leg("bf16_train", "forward AND fused backward of the per-point layers on bf16 MFMA operands (f32 accumulate, "
                                                      "f32 tensors in HBM, f32 BatchNorm statistics / sums); gradient bar: tests/test_bf16_gpu.py")
@@ -479,7 +499,8 @@ def main():
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 forward MFMA operands, f32 accumulate / statistics / backward",
-                                          "bf16_train": "bf16 MFMA operands (forward + fused backward), f32 accumulate / statistics / tensors"}[args.precision], "data": "synthetic",
+                                          "bf16_train": "bf16 MFMA operands (forward + fused backward), f32 accumulate / statistics / tensors",
+                                          "bf16_store": "bf16 MFMA operands + bf16 stored activations, f32 accumulate / statistics / gradients"}[args.precision], "data": "synthetic",
             "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"dp{world}"},
@@ -487,7 +508,7 @@ def main():
             "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
-            "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg,
+            "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
             "train_loop_inclusive": incl, "fps": fps,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS),

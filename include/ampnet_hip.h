@@ -202,6 +202,12 @@ int ampnet_knn_f32(const float *xyz, int n_clouds, int n, int ld, const int32_t 
  * the recomputed activation a and the weights are formed in fp32 and rounded once; accumulation, BatchNorm-backward sums, the
  * K <= 12 input layers, the T-Net FC layers, the attention and every tensor in HBM stay fp32.                                   */
 #define AMPNET_PRECISION_BF16_TRAIN 2
+/* AMPNET_PRECISION_BF16_STORE: AMPNET_PRECISION_BF16_TRAIN, and the activations a train step keeps for its backward (the nine
+ * pre-BatchNorm tensors of the encoder, z2 / z3 of the head) are STORED as bf16 (rounded once from the fp32 accumulator; the
+ * BatchNorm statistics are taken before the rounding): the step moves about a third fewer HBM bytes.  Inputs, outputs (local,
+ * global, feat_T, logits), gradients and parameters stay fp32.  The forward workspace of this mode can only be read by a
+ * backward call made in the same mode.                                                                                        */
+#define AMPNET_PRECISION_BF16_STORE 3
 int ampnet_set_matrix_precision(int mode);
 int ampnet_get_matrix_precision(void);
 

@@ -16,9 +16,10 @@ __device__ bf16x8 tr_operand(const __bf16 *tile, int ld, int row0, int col0, int
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * ld));
-    bf16x8 o;
-    for (int i = 0; i < 4; ++i) { o[i] = __builtin_bit_cast(__bf16, lo[i]); o[4 + i] = __builtin_bit_cast(__bf16, hi[i]); }
-    return o;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    // whole-vector bit casts + one shuffle: an element-by-element short -> __bf16 copy is miscompiled by this hipcc (it keeps only the
+    // first dword of each read)
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __global__ void probe(const float *G, const float *Y, float *C)
 {

@@ -105,7 +105,8 @@ def test_bf16_backward_kernels_close_to_fp32_encoder(synth, params, B, W, N):
     """The SAME fp32 forward (workspace recomputed for each run), then the encoder backward once with fp32 and once with bf16
     operands in the fused layer kernels.  What a bf16 product can promise per layer is a relative 2^-8 per term; the weight
     gradients of the layers whose gradient path has not crossed a T-Net FC BatchNorm yet (conv_6 .. conv_3: first in the backward
-    walk) must agree to 2e-2, everything within the conditioning-limited 0.25 / cosine 0.97 of this model (module docstring)."""
+    walk) must agree to 1e-2 (measured 7e-5 .. 4e-3), every tensor to 3e-2 (measured worst 1e-2: the input T-Net's conv_2, the end of the
+    longest chain), the whole gradient to cosine 0.999 (measured 1.0000)."""
     ops, L = sub("ops"), sub("_lib")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
     b0 = synth.make_buffers(5, params.ENC_BUFFERS)
@@ -139,17 +140,21 @@ def test_bf16_backward_kernels_close_to_fp32_encoder(synth, params, B, W, N):
     first = ["conv_6.weight", "conv_5.weight", "conv_4.weight", "conv_3.weight", "bn_5.weight", "bn_4.weight", "bn_3.weight"]
     print("bf16 backward vs fp32, relative error:", {k: f"{rel[k]:.2e}" for k in first + ["conv_2.weight", "feature_transform.conv_2.weight", "input_transform.conv_2.weight"]})
     for k in first:
-        assert rel[k] <= 2e-2, (k, rel[k])
+        assert rel[k] <= 1e-2, (k, rel[k])                       # measured 7e-5 .. 4e-3
+    gtot_f = np.sqrt(sum((gf[k].double() ** 2).sum().item() for k in gf))
+    for k in gf:                                                 # every tensor: 3e-2 of its norm + 1e-6 of the total (zero-gradient biases)
+        err = (gb[k].double() - gf[k].double()).norm().item()
+        assert err <= 3e-2 * gf[k].double().norm().item() + 1e-6 * gtot_f, (k, rel[k])
     nb = np.sqrt(sum((gb[k].double() ** 2).sum().item() for k in gf))
     nf = np.sqrt(sum((gf[k].double() ** 2).sum().item() for k in gf))
     cos = sum((gb[k].double() * gf[k].double()).sum().item() for k in gf) / (nb * nf)
     print(f"all encoder gradients: |bf16| / |fp32| = {nb / nf:.4f}, cosine {cos:.4f}, worst tensor {max(rel, key=rel.get)} {max(rel.values()):.2e}")
-    assert abs(nb - nf) <= 0.1 * nf and cos > 0.97, (nb, nf, cos)
+    assert abs(nb - nf) <= 0.01 * nf and cos > 0.999, (nb, nf, cos)
 
 
 def test_bf16_backward_kernels_close_to_fp32_head(synth, params):
     """Head backward (conv_3 with the dropout mask, conv_2 with the per-window token bias) with bf16 operands against the fp32
-    kernels on the same fp32 forward: every head gradient and both outputs (d_lo, d_gl) within 2e-2."""
+    kernels on the same fp32 forward: every head gradient and both outputs (d_lo, d_gl) within 1e-2 (measured 2e-3 .. 3e-3)."""
     ops, L = sub("ops"), sub("_lib")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(7, params.HEAD_PARAMS).items()}
     b0 = synth.make_buffers(7, params.HEAD_BUFFERS)
@@ -184,7 +189,82 @@ def test_bf16_backward_kernels_close_to_fp32_head(synth, params):
         L.set_matrix_precision("fp32")
     gf, gb = res["fp32"], res["bf16_train"]
     assert any(not torch.equal(gf[k], gb[k]) for k in gf), "the bf16 backward did not run"
-    rel = {k: _rel(gb[k], gf[k]) for k in gf if gf[k].double().norm().item() > 1e-12}
+    gtot = np.sqrt(sum((gf[k].double() ** 2).sum().item() for k in gf if not k.startswith("__")))
+    # biases in front of a BatchNorm (conv_2.bias, and out_proj.bias through the token path) have an analytically ZERO gradient: what
+    # the kernels return there is rounding noise of either precision, so the bar carries an absolute floor of 1e-6 of the total norm
+    rel = {k: _rel(gb[k], gf[k]) for k in gf}
     print("bf16 head backward vs fp32, relative error:", {k: f"{v:.2e}" for k, v in rel.items()})
-    for k, v in rel.items():
-        assert v <= 2e-2, (k, v)
+    for k in gf:
+        err = (gb[k].double() - gf[k].double()).norm().item()
+        assert err <= 1e-2 * gf[k].double().norm().item() + 1e-6 * gtot, (k, rel[k])
+
+
+# ---- bf16_store: bf16_train + the activations kept for the backward stored as bf16 (precision mode 3) ------------------------------
+def test_bf16_store_step_close_to_bf16_train(synth, params):
+    """Storing the pre-BatchNorm activations as bf16 (a third fewer HBM bytes per step) on top of bf16 MFMA operands: the same
+    train step in mode 'bf16_store' and in mode 'bf16_train'.  Both carry the bf16 forward noise that this model's T-Net FC
+    BatchNorms amplify (test_train_step_close_to_fp32), so the comparison is mode against mode and against fp32:
+    loss terms within 2 % of fp32, the gradient no further from the fp32 gradient than the bf16_train gradient is (x 1.5), the
+    layers behind no T-Net (head conv_4) within 2e-2 (measured 1.1e-2; bf16_train 0.8e-2), train-mode logits no further from the fp32
+    logits than 1.5 x the bf16_train logits are (measured 0.86 vs 0.64 on a span of 4.7)."""
+    T = sub("trainer")
+    L = sub("_lib")
+    pc, tg, cent, _ = synth.sample_batch(812, 64, 256, max_w=3)
+    x = np.ascontiguousarray(pc.transpose(0, 3, 1, 2)); t = np.ascontiguousarray(tg.transpose(0, 2, 1))
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device="cuda")
+    res = {}
+    try:
+        for mode in ("fp32", "bf16_train", "bf16_store"):
+            L.set_matrix_precision(mode)
+            enc, att = _models(synth, params, 0.0)
+            enc.train(); att.train()
+            out = T.forward_backward(enc, att, x, t, cent, cw)
+            torch.cuda.synchronize()
+            res[mode] = (float(out["ce"][0]), float(out["reg"]), out["logits"].double().clone(),
+                         {("e." if m is enc else "a.") + k: p.grad.double().clone() for m in (enc, att) for k, p in m.named_parameters()})
+    finally:
+        L.set_matrix_precision("fp32")
+    ce_f, reg_f, lg_f, gf = res["fp32"]
+
+    def stats(mode):
+        ce, reg, lg, g = res[mode]
+        nf = np.sqrt(sum((gf[k] ** 2).sum().item() for k in gf))
+        nb = np.sqrt(sum((g[k] ** 2).sum().item() for k in gf))
+        cos = sum((g[k] * gf[k]).sum().item() for k in gf) / (nb * nf)
+        err = np.sqrt(sum(((g[k] - gf[k]) ** 2).sum().item() for k in gf)) / nf
+        return dict(ce=abs(ce - ce_f) / abs(ce_f), reg=abs(reg - reg_f) / abs(reg_f), logits=(lg - lg_f).abs().max().item(), cos=cos, err=err,
+                    conv4=(g["a.conv_4.weight"] - gf["a.conv_4.weight"]).norm().item() / gf["a.conv_4.weight"].norm().item())
+    st2, st3 = stats("bf16_train"), stats("bf16_store")
+    print("bf16_train vs fp32:", {k: f"{v:.3e}" for k, v in st2.items()})
+    print("bf16_store vs fp32:", {k: f"{v:.3e}" for k, v in st3.items()})
+    assert all(torch.isfinite(g).all() for g in res["bf16_store"][3].values())
+    assert st3["ce"] <= 2e-2 and st3["reg"] <= 2e-2
+    # train-mode logits of BOTH bf16 modes sit ~0.6 .. 0.9 from fp32 on this seeded model (T-Net FC BatchNorm over B rows; in eval mode
+    # the same tensors agree to 1e-3, test_bf16_store_eval_forward): the storage rounding may add at most half of that again
+    assert st3["logits"] <= 1.5 * st2["logits"] + 5e-2
+    assert st3["conv4"] <= 2e-2
+    assert st3["err"] <= 1.5 * st2["err"] + 1e-2 and st3["cos"] >= st2["cos"] - 0.05
+
+
+def test_bf16_store_eval_forward(synth, params):
+    """Eval forward with bf16-stored intermediates: logits within 3e-2 of the fp32 forward, argmax equal on > 98 % of the points
+    (the bar of the bf16-operand forward, test_eval_forward_close_to_fp32)."""
+    S = sub("pointNet.amp_step")
+    L = sub("_lib")
+    enc, att = _models(synth, params, 0.3)
+    enc.eval(); att.eval()
+    pc, tg, cent, _ = synth.sample_batch(811, 4, 512, max_w=9)
+    x = np.ascontiguousarray(pc.transpose(0, 3, 1, 2)); t = np.ascontiguousarray(tg.transpose(0, 2, 1))
+    try:
+        with torch.no_grad():
+            L.set_matrix_precision("bf16_store")
+            ob = S.forward_batch(enc, att, x, t, cent, None, want_loss=False, want_preds=True)
+            L.set_matrix_precision("fp32")
+            of = S.forward_batch(enc, att, x, t, cent, None, want_loss=False, want_preds=True)
+    finally:
+        L.set_matrix_precision("fp32")
+    lb, lf = ob["logits"].double(), of["logits"].double()
+    err, span = (lb - lf).abs().max().item(), lf.abs().max().item()
+    print(f"bf16_store eval logits: max |diff| {err:.3e} (span {span:.3g})")
+    assert 0.0 < err <= 3e-2 * max(span, 1.0), (err, span)
+    assert (ob["preds"] != of["preds"]).float().mean().item() < 2e-2
