@@ -15,7 +15,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libampnet_hip.so")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-PER_FILE = {"fps.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "augment.hip": ["-ffp-contract=off"]}
+PER_FILE = {"fps.hip": ["-ffp-contract=off"], "knn.hip": ["-ffp-contract=off"], "augment.hip": ["-ffp-contract=off"], "kmeans.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():

@@ -193,57 +193,47 @@ __global__ void km_sort_global_kernel(unsigned long long *__restrict__ keys, siz
 }
 
 // the capacity sweep: pairs in ascending order, a pair is taken when its point is free and its cluster below the cap.
-// One wave: all lanes stage 1024 keys at a time into LDS, lane 0 walks them.  labels[i] = cluster, counts in registers of lane 0.
+// One wave.  A batch of 64 consecutive pairs is FILTERED in parallel against the state before the batch (point already placed, cluster
+// already full: both only ever become more true), the survivors are then replayed in order with wave-uniform control flow, re-checking
+// against the live state in LDS.  Most pairs die in the filter, so the serial part is a few iterations per point.
 __global__ __launch_bounds__(64) void km_sweep_kernel(const unsigned long long *__restrict__ keys, size_t n_pairs, int n, int k, int size_min, int size_max,
                                                       int *__restrict__ labels, int *__restrict__ counts_out, const KmState *st)
 {
     if (st->done) return;
-    __shared__ unsigned long long buf[1024];
     __shared__ uint32_t taken[65536 / 32];
-    __shared__ int s_stop;
+    __shared__ int s_cnt[KM_MAXK];
     const int lane = threadIdx.x;
-    int cnt[KM_MAXK];
-#pragma unroll
-    for (int c = 0; c < KM_MAXK; ++c) cnt[c] = 0;
     for (int w = lane; w < 65536 / 32; w += 64) taken[w] = 0u;
-    int assigned = 0;
+    if (lane < KM_MAXK) s_cnt[lane] = 0;
+    __syncthreads();
+    int assigned = 0;                                             // wave-uniform
     for (int phase = 0; phase < 2; ++phase) {
         const int cap = phase == 0 ? size_min : size_max;
         const int target = phase == 0 ? (size_min * k < n ? size_min * k : n) : n;
-        if (lane == 0) s_stop = assigned >= target;
-        __syncthreads();
-        for (size_t p0 = 0; p0 < n_pairs && !s_stop; p0 += 1024) {
-            for (int e = lane; e < 1024; e += 64) buf[e] = (p0 + e < n_pairs) ? keys[p0 + e] : ~0ull;
-            __syncthreads();
-            if (lane == 0) {
-                const int m = (int)(n_pairs - p0 < 1024 ? n_pairs - p0 : 1024);
-                for (int e = 0; e < m; ++e) {
-                    const uint32_t id = (uint32_t)buf[e];
-                    const int i = (int)(id / KM_MAXK), c = (int)(id % KM_MAXK);
-                    if ((taken[i >> 5] >> (i & 31)) & 1u) continue;
-                    int cc = 0;
-#pragma unroll
-                    for (int q = 0; q < KM_MAXK; ++q) cc = (q == c) ? cnt[q] : cc;       // registers: no run-time indexing
-                    if (cc >= cap) continue;
-#pragma unroll
-                    for (int q = 0; q < KM_MAXK; ++q) cnt[q] += (q == c) ? 1 : 0;
-                    taken[i >> 5] |= 1u << (i & 31);
-                    labels[i] = c;
-                    if (++assigned >= target) {
-                        s_stop = 1;
-                        break;
-                    }
+        for (size_t p0 = 0; p0 < n_pairs && assigned < target; p0 += 64) {
+            const bool valid = p0 + lane < n_pairs;
+            const uint32_t id = valid ? (uint32_t)keys[p0 + lane] : 0u;
+            const int i = (int)(id / KM_MAXK), c = (int)(id % KM_MAXK);
+            const bool live = valid && !((taken[i >> 5] >> (i & 31)) & 1u) && s_cnt[c] < cap;
+            unsigned long long mask = __ballot(live);
+            while (mask && assigned < target) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int ib = __builtin_amdgcn_readlane(i, b), cb = __builtin_amdgcn_readlane(c, b);
+                const uint32_t word = taken[ib >> 5];
+                const int cc = s_cnt[cb];
+                if (((word >> (ib & 31)) & 1u) || cc >= cap) continue;      // placed / filled earlier in this batch
+                if (lane == 0) {
+                    taken[ib >> 5] = word | (1u << (ib & 31));
+                    s_cnt[cb] = cc + 1;
+                    labels[ib] = cb;
                 }
+                __builtin_amdgcn_wave_barrier();
+                ++assigned;
             }
-            __syncthreads();
         }
-        __syncthreads();
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < KM_MAXK; ++q)
-            if (q < k) counts_out[q] = cnt[q];
-    }
+    if (lane < k) counts_out[lane] = s_cnt[lane];
 }
 
 // new centres = cluster means (block = cluster; double sums in a fixed order), centre shift, inertia of the assignment w.r.t. the OLD centres
@@ -327,6 +317,9 @@ __global__ __launch_bounds__(KM_T) void km_control_kernel(const float *__restric
         for (int e = tid; e < 3 * k; e += KM_T) best_C[e] = C[e];
     }
 }
+
+// the loop of an init is over: open the gate again for the final assignment
+__global__ void km_reopen_kernel(KmState *st) { st->done = 0; }
 
 size_t km_pow2(size_t x)
 {

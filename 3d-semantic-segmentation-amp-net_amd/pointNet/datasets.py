@@ -95,3 +95,43 @@ class LidarDataset4Test(data.Dataset):
         pc[:, 0] = pc[:, 0] * 2 - 1
         pc[:, 1] = pc[:, 1] * 2 - 1
         return pc, filename
+
+
+class LidarDatasetExpanded(data.Dataset):
+    """Single-window dataset of the baseline PointNet (pointNet/datasets.py:145-292): a file = pickled numpy [n, >= 10] rows
+    (x, y, HAG, class, I, R, G, B, NIR, NDVI, ...); noise classes removed, resampled to number_of_points (numpy RNG: choice when more,
+    duplicates when fewer), labels from column 3, features = columns 0-2, 4-9 with x, y <- 2 v - 1.
+    __getitem__ -> (pc [n, 9] float32 tensor, labels [n] LongTensor, filename) for task 'segmentation'."""
+    NUM_CLASSIFICATION_CLASSES = 2
+    POINT_DIMENSION = 2
+
+    def __init__(self, dataset_folder, task='classification', number_of_points=None, files=None, fixed_num_points=True, allow_pickle=None):
+        self.dataset_folder = dataset_folder
+        self.task = task
+        self.n_points = number_of_points
+        self.files = files
+        self.fixed_num_points = fixed_num_points
+        self.allow_pickle = allow_pickle
+        self.classes_mapping = {}
+        self.paths_files = [os.path.join(self.dataset_folder, f) for f in self.files]
+
+    def __len__(self):
+        return len(self.paths_files)
+
+    def __getitem__(self, index):
+        filename = self.paths_files[index]
+        pc = np.asarray(load_numpy_pickle(filename, self.allow_pickle), dtype=np.float32)
+        for code in NOISE_CLASSES:
+            pc = pc[pc[:, 3] != code]
+        if self.fixed_num_points and pc.shape[0] > self.n_points:
+            pc = pc[np.random.choice(pc.shape[0], self.n_points), :]
+        if self.fixed_num_points and 0 < pc.shape[0] < self.n_points:
+            extra = np.random.randint(0, pc.shape[0], self.n_points - pc.shape[0])
+            pc = np.concatenate([pc, pc[extra, :]], axis=0)
+        if self.task != 'segmentation':
+            raise NotImplementedError("only the segmentation task is built (SURVEY.md section 8: classification is out of scope)")
+        labels = segmentation_labels(pc[:, 3])
+        pc = torch.from_numpy(np.concatenate((pc[:, :3], pc[:, 4:10]), axis=1))
+        pc[:, 0] = pc[:, 0] * 2 - 1
+        pc[:, 1] = pc[:, 1] * 2 - 1
+        return pc, labels, filename

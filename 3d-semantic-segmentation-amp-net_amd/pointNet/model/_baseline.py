@@ -1,7 +1,9 @@
 """Shared machinery of the two baseline PointNet drop-ins (pointnet.py, light_pointnet_256.py): parameter holders with
-the reference's state_dict keys and the eval forward through the C ABI (include/ampnet_hip.h:
-ampnet_pointnet_seg_fwd_f32, csrc/baseline.hip).  SURVEY row a12: BASELINE.json config 1 is the reference's CPU
-plumbing case; only the eval forward runs on the HIP path, training this model raises."""
+the reference's state_dict keys, the eval forward (ampnet_pointnet_seg_fwd_f32, csrc/baseline.hip) and the train-mode
+forward / backward (ampnet_pointnet_seg_train_fwd_f32 / ampnet_pointnet_seg_bwd_f32, csrc/baseline_train.hip) behind a
+torch.autograd.Function, so that the reference's own loop -- logits, feat_T = net(pc); loss.backward(); optimizer.step()
+(pointNet/baseline/train_segmentation.py:274-328) -- runs on the HIP path.  SURVEY row a12 / BASELINE.json config 1: the
+reference's plumbing case, built for parity, not tuned."""
 import ctypes
 
 import torch
@@ -92,11 +94,30 @@ class SegHolder(nn.Module):
             self._key, self._arr, self._keep = key, arr, tensors
         return self._arr
 
+    def _train_tables(self):
+        """(parameters in autograd order, layer pointer table, a function that builds the gradient pointer table)."""
+        layers = self.base_pointnet.layers() + [(self.conv_1, self.bn_1), (self.conv_2, self.bn_2),
+                                                (self.conv_3, self.bn_3), (self.conv_4, None)]
+        params, slots = [], []                      # slots[i] = indices into params of (weight, bias, bn.weight, bn.bias) or -1
+        for lin, bn in layers:
+            idx = []
+            for t in (lin.weight, getattr(lin, "bias", None), None if bn is None else bn.weight, None if bn is None else bn.bias):
+                if t is None:
+                    idx.append(-1)
+                else:
+                    idx.append(len(params))
+                    params.append(t)
+            slots.append(idx)
+        return params, slots
+
     def forward(self, x):
         """x [B, N, 9] -> (logits [B, num_classes, N], feature_transform [B, 64, 64])."""
         if self.training:
-            raise _lib.AmpnetError("the baseline PointNet is eval-only on the HIP path (BASELINE.json config 1 is the "
-                                   "reference's CPU plumbing case); call .eval()")
+            _lib.require_gpu(x, "x")
+            if x.dim() != 3 or x.shape[2] != 9 or x.dtype != torch.float32:
+                raise _lib.AmpnetError(f"SegmentationPointNet: x must be [B, N, 9] float32, got {tuple(x.shape)} {x.dtype}")
+            params, slots = self._train_tables()
+            return _BaselineFn.apply(self, slots, x.contiguous(), *params)
         _lib.require_gpu(x, "x")
         if x.dim() != 3 or x.shape[2] != 9 or x.dtype != torch.float32:
             raise _lib.AmpnetError(f"SegmentationPointNet: x must be [B, N, 9] float32, got {tuple(x.shape)} {x.dtype}")
@@ -115,3 +136,51 @@ class SegHolder(nn.Module):
                                                ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
         _lib.check(rc, "ampnet_pointnet_seg_fwd_f32")
         return logits, feat_T
+
+
+class _BaselineFn(torch.autograd.Function):
+    """Train-mode forward (batch statistics, running-statistics update) and backward of SegmentationPointNet through the C ABI.
+    Every forward owns its tape (workspace) until its backward has run."""
+
+    @staticmethod
+    def forward(ctx, module, slots, x, *params):
+        B, N, _ = x.shape
+        dev = x.device
+        L = _lib.lib()
+        L.ampnet_pointnet_seg_train_workspace_bytes.restype = ctypes.c_size_t
+        need = L.ampnet_pointnet_seg_train_workspace_bytes(module.VARIANT, B, N, module.num_classes)
+        ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        logits = torch.empty((B, module.num_classes, N), dtype=torch.float32, device=dev)
+        feat_T = torch.empty((B, 64, 64), dtype=torch.float32, device=dev)
+        table = module._layer_table()
+        with torch.cuda.device(dev):
+            rc = L.ampnet_pointnet_seg_train_fwd_f32(table, module.VARIANT, _lib.ptr(x), B, N, module.num_classes, _lib.ptr(logits),
+                                                     _lib.ptr(feat_T), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev))
+        _lib.check(rc, "ampnet_pointnet_seg_train_fwd_f32")
+        for m in module.modules():
+            if isinstance(m, _BN):
+                m.num_batches_tracked += 1
+        ctx.save_for_backward(x)
+        ctx.meta = (module, slots, ws, [tuple(p.shape) for p in params])
+        ctx.mark_non_differentiable()
+        return logits, feat_T
+
+    @staticmethod
+    def backward(ctx, dlogits, d_feat_T):
+        module, slots, ws, shapes = ctx.meta
+        x, = ctx.saved_tensors
+        B, N, _ = x.shape
+        dev = x.device
+        grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
+        garr = (ctypes.c_void_p * (4 * N_LAYERS))()
+        for i, idx in enumerate(slots):
+            for j, k in enumerate(idx):
+                garr[4 * i + j] = None if k < 0 else grads[k].data_ptr()
+        dl = dlogits.contiguous().float()
+        dft = None if d_feat_T is None else d_feat_T.contiguous().float()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ampnet_pointnet_seg_bwd_f32(module._layer_table(), garr, module.VARIANT, _lib.ptr(x), B, N, module.num_classes,
+                                                        _lib.ptr(dl), _lib.ptr(dft), _lib.ptr(ws), ctypes.c_size_t(ws.numel()), _lib.stream_ptr(dev))
+        _lib.check(rc, "ampnet_pointnet_seg_bwd_f32")
+        ctx.meta = None
+        return (None, None, None) + tuple(grads)

@@ -81,6 +81,98 @@ def gather_rows(pc, idx):
     return out
 
 
+def kmeans_balanced(feat, k, size_min, size_max, n_init=5, max_iter=10, tol=1e-2, seed=0):
+    """Size-constrained k-means on the GPU (include/ampnet_hip.h: ampnet_kmeans_balanced_f32; BUILD-DEFINED spec, the reference uses
+    the third-party KMeansConstrained here).  feat [n, 3] float32 GPU tensor -> (labels int32 [n], centres [k, 3], inertia float)."""
+    _lib.require_gpu(feat, "feat")
+    f = feat.float().contiguous()
+    if f.dim() != 2 or f.shape[1] != 3:
+        raise _lib.AmpnetError(f"kmeans_balanced: feat must be [n, 3], got {tuple(feat.shape)}")
+    n = f.shape[0]
+    L = _lib.lib()
+    L.ampnet_kmeans_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_kmeans_workspace_bytes(n, int(k))
+    if need == 0:
+        raise _lib.AmpnetError(f"kmeans_balanced: n={n}, k={k} out of range (k <= 32, n <= 65536)")
+    ws = torch.empty(need, dtype=torch.uint8, device=f.device)
+    labels = torch.empty(n, dtype=torch.int32, device=f.device)
+    centres = torch.empty((int(k), 3), dtype=torch.float32, device=f.device)
+    inertia = torch.zeros(1, dtype=torch.float64, device=f.device)
+    with torch.cuda.device(f.device):
+        rc = L.ampnet_kmeans_balanced_f32(_lib.ptr(f), n, int(k), int(size_min), int(size_max), int(n_init), int(max_iter), ctypes.c_float(tol),
+                                          ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(labels), _lib.ptr(centres), _lib.ptr(inertia), _lib.ptr(ws),
+                                          ctypes.c_size_t(need), _lib.stream_ptr(f.device))
+    _lib.check(rc, "ampnet_kmeans_balanced_f32")
+    return labels, centres, float(inertia.item())
+
+
+def get_cluster_centroid(pc):
+    """mean x, y of a cluster [n, >= 2] -> tensor [2] (utils/utils.py:538-543)."""
+    return torch.stack([pc[:, 0].mean(0), pc[:, 1].mean(0)], dim=0)
+
+
+def kmeans_clustering(in_pc, n_points=2048, get_centroids=True, max_clusters=18, out_path='', file_name='', device="cuda", seed=0):
+    """Drop-in for utils/utils.py:473-535: clusters of >= n_points points of one point cloud [1, n, dim] / [n, dim] by constrained k-means on
+    (x, y, NDVI) = columns (0, 1, 8).  Returns (cluster_lists: list of [n_i, dim] tensors, centroids [k, 2]); optionally saves both like the
+    reference (torch.save instead of pickle.dump: amp_test loads them without unpickling).  The clustering itself runs on the MI355X
+    (kmeans_balanced above) instead of the third-party KMeansConstrained: same contract (k = floor(n / n_points) <= max_clusters
+    clusters, every cluster >= n_points), a different -- build-defined, deterministic -- assignment."""
+    in_pc = torch.as_tensor(in_pc)
+    if in_pc.dim() == 3:
+        in_pc = in_pc.squeeze(0)
+    cluster_lists, centroids = [], []
+    if in_pc.shape[0] >= 2 * n_points:
+        k = min(int(in_pc.shape[0] // n_points), max_clusters)
+        feat = in_pc[:, [0, 1, 8]].float().to(device)
+        labels, _, _ = kmeans_balanced(feat, k, n_points, in_pc.shape[0], n_init=5, max_iter=10, tol=0.01, seed=seed)
+        labels = labels.cpu()
+        for c in range(k):                       # clusters in ascending label order (the reference groups by sorted label)
+            pts = in_pc[labels == c]
+            cluster_lists.append(pts)
+            if get_centroids:
+                centroids.append(get_cluster_centroid(pts))
+    else:
+        cluster_lists.append(in_pc)
+        if get_centroids:
+            centroids.append(get_cluster_centroid(in_pc))
+    centroids = torch.stack(centroids, dim=0) if centroids else torch.FloatTensor()
+    if out_path:
+        os.makedirs(out_path, exist_ok=True)
+        torch.save(cluster_lists, os.path.join(out_path, file_name + '_clusters_list') + '.pkl')
+        torch.save(centroids, os.path.join(out_path, file_name + '_centroids') + '.pkl')
+    return cluster_lists, centroids
+
+
+def split_kmeans_windows(pc, n_points=2048, max_clusters=9, device="cuda", seed=0):
+    """The array part of data_proc/3_kmeans.py:27-116 split_kmeans: a point cloud [n, D] (numpy) -> windows tensor [n_points, D, k] of
+    exactly n_points points each (k = ceil(n / n_points) <= max_clusters; surplus points sampled away with random.sample, missing ones
+    duplicated with numpy's RNG, like the reference), grouped by size-constrained k-means (size_min = size_max = n_points) on
+    (x, y, NDVI) = columns (0, 1, 9).  Clouds below 2 * n_points: one window (random.sample down to n_points when larger)."""
+    import random
+    pc = np.asarray(pc, dtype=np.float32)
+    if pc.shape[0] >= 2 * n_points:
+        in_pc = pc
+        k = int(np.ceil(in_pc.shape[0] / n_points))
+        if k > max_clusters:
+            k = max_clusters
+            ix = random.sample(range(in_pc.shape[0]), n_points * max_clusters)
+            in_pc = in_pc[ix, :]
+        elif in_pc.shape[0] < n_points * k:
+            extra = np.random.randint(0, in_pc.shape[0], n_points * k - in_pc.shape[0])
+            in_pc = np.concatenate([in_pc, in_pc[extra, :]], axis=0)
+        if in_pc.shape[0] % n_points != 0:
+            in_pc = in_pc[:n_points * (in_pc.shape[0] // n_points), :]
+        feat = torch.from_numpy(np.ascontiguousarray(in_pc[:, [0, 1, 9]])).to(device)
+        labels, _, _ = kmeans_balanced(feat, k, n_points, n_points, n_init=5, max_iter=10, tol=1e-2, seed=seed)
+        labels = labels.cpu().numpy()
+        t = torch.from_numpy(in_pc)
+        return torch.stack([t[labels == c] for c in range(k)], dim=2)        # [n_points, D, k]
+    if pc.shape[0] > n_points:
+        ix = random.sample(range(pc.shape[0]), n_points)
+        pc = pc[ix, :]
+    return torch.from_numpy(pc).unsqueeze(2)
+
+
 def fps(pc, n_samples, device="cuda"):
     """Drop-in for the reference's fps(pc, n_samples): pc [N, D] -> the sampled rows (all D columns) in
     selection order.  numpy in -> numpy out (like the reference); a GPU tensor in -> GPU tensor out."""
@@ -135,6 +227,17 @@ def get_labels(cluster_lists):
     labels 0 background, 1 tower, 2 lines, 3 low/medium vegetation, 4 high vegetation (utils/utils.py:546-579)."""
     from ..pointNet.datasets import segmentation_labels
     return [segmentation_labels(torch.as_tensor(c).squeeze(0)[:, 9]) for c in cluster_lists]
+
+
+def save_checkpoint(name, epoch, epochs_since_improvement, model, optimizer, accuracy, batch_size, learning_rate, n_points,
+                    weighing_method=None):
+    """The baseline's checkpoint (utils/utils.py:441-456): same dict keys, same file name pointNet/checkpoints/checkpoint_<name>.pth."""
+    state = {'model': model.state_dict(), 'optimizer': optimizer.state_dict(), 'batch_size': batch_size, 'lr': learning_rate,
+             'number_of_points': n_points, 'epoch': epoch, 'epochs_since_improvement': epochs_since_improvement, 'accuracy': accuracy,
+             'weighing_method': weighing_method}
+    os.makedirs("pointNet/checkpoints", exist_ok=True)
+    torch.save(state, 'pointNet/checkpoints/checkpoint_' + name + '.pth')
+    return 'pointNet/checkpoints/checkpoint_' + name + '.pth'
 
 
 def save_checkpoint_segmen_model(name, task, epoch, epochs_since_improvement, base_pointnet, segmen_model,

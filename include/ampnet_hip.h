@@ -190,6 +190,19 @@ int ampnet_augment_f32(const float *pc, const long long *targets, const int32_t 
 int ampnet_knn_f32(const float *xyz, int n_clouds, int n, int ld, const int32_t *centres, int s, int k, int32_t *out,
                    void *stream);
 
+/* ---- size-constrained k-means: the window grouping step in front of the path --------------------------
+ * replaces the calls of the third-party k_means_constrained.KMeansConstrained at data_proc/3_kmeans.py:78-82 (size_min = size_max =
+ * n_points, n_init 5, max_iter 10, tol 1e-2, features x, y, NDVI) and utils/utils.py:500-505 (size_min only).  That package is not part
+ * of the reference repository: parity is UNPINNED; the algorithm below is this build's spec (csrc/kmeans.hip, oracle/kmeans_oracle.py):
+ * farthest-point seeding, greedy capacity-constrained assignment in ascending (distance, point, cluster) order (every cluster first gets
+ * size_min points, the rest go where capacity size_max allows), means, stop at centre shift <= tol * mean feature variance, best of n_init.
+ *   feat     [n, 3] float32 device     labels  [n] int32 out     centres [k, 3] float32 out     inertia: device double out (may be NULL)
+ *   1 <= k <= 32, k <= n <= 65536, size_min * k <= n <= size_max * k                                                                   */
+size_t ampnet_kmeans_workspace_bytes(int n, int k);
+int ampnet_kmeans_balanced_f32(const float *feat, int n, int k, int size_min, int size_max, int n_init, int max_iter, float tol,
+                               uint32_t seed, int32_t *labels, float *centres, double *inertia, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /* ---- matrix-core operand precision (process-wide) -----------------------------------------------------------
  * AMPNET_PRECISION_F32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products -- the mode every parity figure is quoted in.
  * AMPNET_PRECISION_BF16: the per-point layers of ampnet_encoder_fwd_f32 / ampnet_head_fwd_f32 round their MFMA operands
@@ -227,6 +240,20 @@ int ampnet_get_matrix_precision(void);
 size_t ampnet_pointnet_seg_workspace_bytes(int variant, int B, int N, int n_classes);
 int ampnet_pointnet_seg_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N,
                                 int n_classes, float *logits, float *feat_T, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* ---- a12: the same model in train mode (BASELINE.json config 1 end to end) --------------------------------------------------
+ * replaces SegmentationPointNet.forward under module.train() + loss.backward() as pointNet/baseline/train_segmentation.py:274-328 drives
+ * them: batch-statistics BatchNorm (running statistics updated in place through layers_host, momentum 0.1, unbiased variance), and
+ * the gradients of every parameter from (dlogits [B, C, N], d_feat_T [B, 64, 64] or NULL).  The forward keeps its activations in
+ * `workspace` (ampnet_pointnet_seg_train_workspace_bytes); the backward must get the same, untouched workspace.  B >= 2.
+ *   grads_host   [AMPNET_POINTNET_LAYERS * 4] device pointers per layer {d weight, d bias, d bn.weight, d bn.bias}, NULL where the
+ *                layer has no such parameter; every gradient is overwritten                                                    */
+size_t ampnet_pointnet_seg_train_workspace_bytes(int variant, int B, int N, int n_classes);
+int ampnet_pointnet_seg_train_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N, int n_classes,
+                                      float *logits, float *feat_T, void *workspace, size_t workspace_bytes, void *stream);
+int ampnet_pointnet_seg_bwd_f32(const float *const *layers_host, float *const *grads_host, int variant, const float *x, int B, int N,
+                                int n_classes, const float *dlogits, const float *d_feat_T, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
 /* ---- a7: optimiser -----------------------------------------------------------------------------------------

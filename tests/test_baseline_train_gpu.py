@@ -1,0 +1,155 @@
+"""Baseline PointNet TRAINING on the HIP path (BASELINE.json config 1: batch 4, N = 512, 9 features, 5 classes)
+against what the reference's own train_loop (pointNet/baseline/train_segmentation.py:274-328) returned on the same seeded batch
+(tests/golden/baseline_train.npz, baseline_light_train.npz: made by tests/golden/make_golden.py:sec_baseline_train).
+Bars: loss terms 1e-4 (step 1) / 2e-3 (step 2, behind one Adam update); gradient norms and the small gradients stored in full 2e-2 of
+their norm (B = 4 rows in the T-Net FC BatchNorms: the reference's own fp32 noise, tests/test_step_gpu.py); parameter sums after Adam."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import sub                           # noqa: E402
+from helpers import baseline_state                 # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(synth, variant):
+    if variant == "baseline_train":
+        M = sub("pointNet.model.pointnet")
+        net, base = M.SegmentationPointNet(num_classes=5, point_dimension=3, device="cuda"), 9000
+    else:
+        M = sub("pointNet.model.light_pointnet_256")
+        net, base = M.SegmentationPointNet(num_classes=5, point_dimension=2, device="cuda"), 9500
+    table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in baseline_state(synth, table, base).items()}, strict=False)
+    return net
+
+
+@pytest.mark.parametrize("variant", ["baseline_train", "baseline_light_train"])
+def test_baseline_train_loop_matches_reference(golden, synth, variant):
+    B = sub("pointNet.baseline_seg")
+    g = golden(variant)
+    net = _net(synth, variant)
+    x = synth.windows(81, 4, 512)
+    t = synth.labels_for(x, 81)
+    t[0, :40] = -1
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).cuda(), reduction="mean", ignore_index=-1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+    for step in (1, 2):
+        np.random.seed(2000 + step)
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * 4)
+        m, tpc, preds, _ = B.train_loop(data, opt, ce, net, None, True, 0, 0)
+        rt = 1e-4 if step == 1 else 2e-3
+        for k, key in (("ce", "ce_loss"), ("reg", "reg_loss"), ("loss", "loss")):
+            want = float(g[f"s{step}_{k}"].reshape(-1)[0])
+            assert abs(m[key].item() - want) <= rt * abs(want), (step, k, m[key].item(), want)
+        losses.append(m["loss"].item())
+        assert (preds.numpy() != g[f"s{step}_preds"]).mean() < 5e-3
+        gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith(f"s{step}_gnorm/")))
+        for k, p in net.named_parameters():
+            gn = g[f"s{step}_gnorm/{k}"]
+            got = p.grad.double()
+            assert abs(got.norm().item() - gn[0]) <= 2e-2 * gn[0] + 1e-5 * gtot, (step, k, got.norm().item(), gn[0])
+            key = f"s1_grad/{k}"
+            if step == 1 and key in g.files:
+                err = np.linalg.norm(got.cpu().numpy() - g[key].astype(np.float64))
+                assert err <= 2e-2 * gn[0] + 1e-5 * gtot, (k, err, gn[0])
+            ps = g[f"s{step}_psum/{k}"]
+            np.testing.assert_allclose(p.detach().double().abs().sum().item(), ps[1], rtol=2e-4, atol=2.1e-3 * step * max(1.0, 0.02 * p.numel()), err_msg=k)
+    assert losses[1] < losses[0]                                  # "runs end-to-end; loss decreases"
+    sd = net.state_dict()
+    for k in sd:
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"final_buf/{k}"], rtol=1e-2, atol=5e-3, err_msg=k)
+    assert int(net.bn_1.num_batches_tracked) == 2
+    np.random.seed(2009)
+    with torch.no_grad():
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * 4)
+        m, _, preds, _ = B.train_loop(data, opt, ce, net, None, False, 0, 0)
+    want = float(g["eval_ce"].reshape(-1)[0])
+    assert abs(m["ce_loss"].item() - want) <= 5e-3 * abs(want)    # behind two noisy Adam steps
+    assert (preds.numpy() != g["eval_preds"]).mean() < 2e-2
+
+
+def test_baseline_gradients_match_float64_autograd(synth):
+    """The HIP backward against torch autograd of the same graph in float64 on the CPU (the reference module itself is not on the GPU
+    box): a compact float64 restatement of pointnet.py built from torch.nn.functional ops, same weights, same batch."""
+    import torch.nn.functional as F
+    net = _net(synth, "baseline_train")
+    net.train()
+    x = torch.from_numpy(synth.windows(82, 4, 256)).cuda()
+    t = torch.from_numpy(synth.labels_for(synth.windows(82, 4, 256), 82)).cuda()
+    ce = torch.nn.CrossEntropyLoss(weight=torch.DoubleTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
+    sd64 = {k: v.detach().double().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in net.state_dict().items()}
+    logits, ft = net(x)
+    loss = torch.nn.functional.cross_entropy(logits, t, weight=torch.tensor([1., 2., 2., 1., 1.], device="cuda"), ignore_index=-1) \
+        + 0.001 * torch.norm(torch.eye(64, device="cuda") - torch.bmm(ft, ft.transpose(2, 1)))
+    loss.backward()
+
+    def lin_bn(h, pre, conv, bn, relu=True):
+        w = sd64[pre + conv + ".weight"]
+        h = h @ w.reshape(w.shape[0], -1).t() + sd64[pre + conv + ".bias"]
+        if bn:
+            mu, var = h.mean(0), h.var(0, unbiased=False)
+            h = (h - mu) / torch.sqrt(var + 1e-5) * sd64[pre + bn + ".weight"] + sd64[pre + bn + ".bias"]
+        return torch.relu(h) if relu else h
+
+    def tnet(h, pre, k, Bn, N):
+        h = lin_bn(lin_bn(lin_bn(h, pre, "conv_1", "bn_1"), pre, "conv_2", "bn_2"), pre, "conv_3", "bn_3")
+        p = h.reshape(Bn, N, -1).max(1).values
+        p = lin_bn(lin_bn(p, pre, "fc_1", "bn_4"), pre, "fc_2", "bn_5")
+        return lin_bn(p, pre, "fc_3", None, relu=False).reshape(Bn, k, k) + torch.eye(k, dtype=torch.float64)
+    xd = x.double().cpu()
+    Bn, N = xd.shape[0], xd.shape[1]
+    T3 = tnet(xd[:, :, :3].reshape(-1, 3), "base_pointnet.input_transform.", 3, Bn, N)
+    h = torch.cat([torch.bmm(xd[:, :, :3], T3), xd[:, :, 3:]], 2).reshape(-1, 9)
+    h = lin_bn(lin_bn(h, "base_pointnet.", "conv_1", "bn_1"), "base_pointnet.", "conv_2", "bn_2")
+    T64 = tnet(h, "base_pointnet.feature_transform.", 64, Bn, N)
+    local = torch.bmm(h.reshape(Bn, N, 64), T64).reshape(-1, 64)
+    h = lin_bn(lin_bn(lin_bn(local, "base_pointnet.", "conv_3", "bn_3"), "base_pointnet.", "conv_4", "bn_4"), "base_pointnet.", "conv_5", "bn_5")
+    glob = h.reshape(Bn, N, -1).max(1).values
+    emb = torch.cat([glob[:, None, :].expand(Bn, N, glob.shape[1]).reshape(Bn * N, -1), local], 1)
+    h = lin_bn(lin_bn(lin_bn(emb, "", "conv_1", "bn_1"), "", "conv_2", "bn_2"), "", "conv_3", "bn_3")
+    lg = lin_bn(h, "", "conv_4", None, relu=False).reshape(Bn, N, -1).transpose(1, 2)
+    l64 = ce(lg, t.cpu()) + 0.001 * torch.norm(torch.eye(64, dtype=torch.float64) - torch.bmm(T64, T64.transpose(2, 1)))
+    l64.backward()
+    assert abs(loss.item() - l64.item()) <= 1e-4 * abs(l64.item())
+    assert (logits.double().cpu() - lg.detach()).abs().max().item() <= 1e-3
+    gtot = np.sqrt(sum(float(v.grad.norm()) ** 2 for v in sd64.values() if v.grad is not None))
+    worst = 0.0
+    for k, p in net.named_parameters():
+        w = sd64[k].grad
+        err = (p.grad.double().cpu().reshape(w.shape) - w).norm().item()
+        worst = max(worst, err / (w.norm().item() + 1e-5 * gtot))
+        assert err <= 3e-2 * w.norm().item() + 1e-5 * gtot, (k, err, w.norm().item())
+    print(f"baseline PointNet backward vs float64 autograd: worst relative error {worst:.2e}")
+
+
+def test_baseline_training_driver_reduces_loss(synth, tmp_path, monkeypatch):
+    """train() / test() drop-ins end to end on a synthetic dataset in the reference's file formats (config 1 sizes)."""
+    import pickle
+    B = sub("pointNet.baseline_seg")
+    data_dir, lists = tmp_path / "data", tmp_path / "lists"
+    data_dir.mkdir(); lists.mkdir()
+    names = {"train": [], "val": [], "test": []}
+    for i in range(14):
+        arr = synth.kmeans_file_tensor(1500 + i, 600, 1, noise_frac=0.02)[:, :, 0]
+        with open(data_dir / f"t{i}.pkl", "wb") as f:
+            pickle.dump(arr, f)
+        names["train" if i < 8 else ("val" if i < 12 else "test")].append(f"t{i}.pkl")
+    for k, v in names.items():
+        (lists / f"{k}_seg_files.txt").write_text("\n".join(v) + "\n")
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(0); torch.manual_seed(0)
+    hist = B.train(str(data_dir), str(lists), str(tmp_path), 512, 4, 6, 1e-3, 0, None, False, model="pointnet")
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"]
+    cks = sorted((tmp_path / "pointNet" / "checkpoints").glob("checkpoint_*.pth"))
+    assert cks, "no checkpoint written"
+    out = B.test(str(data_dir), 512, str(tmp_path), 0, str(cks[-1]), str(lists), model="pointnet")
+    assert 0.0 <= out["accuracy"] <= 1.0 and np.isfinite(out["mean_iou"])
