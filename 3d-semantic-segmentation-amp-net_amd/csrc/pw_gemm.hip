@@ -17,6 +17,7 @@
 //     order, both operands agree on it.
 //   * weights (<= 128 x 256 fp32 = 133 KB) are staged in LDS once per workgroup and reused for every row tile
 //     of the workgroup's chunk; A fragments are prefetched one 128-byte line per row ahead of the MFMAs.
+#include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
 
@@ -53,7 +54,9 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // prologue and the epilogue stay fp32 (ampnet_set_matrix_precision).  Lane (r, h) then owns k = 16 s + 8 h .. + 7 of step s.
 // ABF / ZBF (BF kernels only): A / Z are bf16 tensors (activation storage of precision mode 3); compile-time so that the K loop
 // stays one basic block (as a run-time flag the bf16 kernels ran 10-35 % slower).
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false>
+// PIPE (fp32 path, the default; AMPNET_PW_PIPE=0 turns it off): the operands of a k step are read / computed one step ahead under the MFMAs of the
+// current step (scratch/ab_pw_pipe.py compares the two forms on one box in one process).
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
     constexpr int CB = 32 * NT;
@@ -203,10 +206,39 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     };
     int tile = wave;
     if (tile < ntiles) load_frags(a_cur, tile, 0);
+    auto pro_apply = [&](f32x4 v, const f32x4 &sc, const f32x4 &sh, int row, int k0) -> f32x4 {
+        if (PRO) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
+            if (PRO == 2) {
+                const uint32_t e0 = (uint32_t)row * (uint32_t)CIN + (uint32_t)k0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (mix32((e0 + i) ^ dbase) >= dthr) ? v[i] * dscale : 0.f;
+            }
+        }
+        return v;
+    };
+    auto arow_of = [&](int t_) -> int {
+        const int row0_ = row_begin + t_ * 32;
+        return row0_ + min(r, min(32, row_end - row0_) - 1);
+    };
+    f32x4 pbv[NT], pav = {0.f, 0.f, 0.f, 0.f};            // PIPE: operands of the step about to run
+    if (PIPE && !BF && tile < ntiles) {
+        const int k0 = 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pbv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (PRO) {
+            sc = *reinterpret_cast<const f32x4 *>(sPro + k0);
+            sh = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0);
+        }
+        pav = pro_apply(a_cur[0], sc, sh, arow_of(tile), k0);
+    }
     for (; tile < ntiles; tile += PW_NW) {
         const int row0 = row_begin + tile * 32;
         const int valid = min(32, row_end - row0);
         const int arow = row0 + min(r, valid - 1);
+        const int arow_next = (tile + PW_NW < ntiles) ? arow_of(tile + PW_NW) : arow;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -262,8 +294,57 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw[t], acc[t], 0, 0, 0);
                 }
             }
+            if (PIPE && !BF) {
 #pragma unroll
-            for (int j = 0; j < (BF ? 0 : 4); ++j) {
+                for (int j = 0; j < 4; ++j) {
+                    // the step after this one: (kb, j + 1), or step 0 of the next k block / of this wave's next tile
+                    const bool wrap = j == 3;
+                    const int k0n = (wrap ? (32 * (kb + 1)) % CIN : 32 * kb + 8 * (j + 1)) + 4 * h;
+                    const int row_n = (wrap && kb == NBLK - 1) ? arow_next : arow;
+                    f32x4 sc_n = {1.f, 1.f, 1.f, 1.f}, sh_n = {0.f, 0.f, 0.f, 0.f}, av_n = pav;
+                    if constexpr (NT == 4) {
+                        // two groups of two column tiles, the MFMAs of a group alternate accumulators; a group's weights are dead once its
+                        // eight MFMAs are issued and are re-fetched for the next step in the shadow of the other group
+#pragma unroll
+                        for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int t = 2 * gq; t < 2 * gq + 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav[i], pbv[t][i], acc[t], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int t = 2 * gq; t < 2 * gq + 2; ++t) pbv[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0n);
+                            if (PRO && gq == 0) {
+                                sc_n = *reinterpret_cast<const f32x4 *>(sPro + k0n);
+                                sh_n = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0n);
+                            }
+                            if (gq == 1) av_n = pro_apply(wrap ? a_nxt[0] : a_cur[(j + 1) & 3], sc_n, sh_n, row_n, k0n);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        f32x4 bn[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) bn[t] = *reinterpret_cast<const f32x4 *>(sW + (32 * t + r) * LDW + k0n);
+                        if (PRO) {
+                            sc_n = *reinterpret_cast<const f32x4 *>(sPro + k0n);
+                            sh_n = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0n);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav[i], pbv[t][i], acc[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        av_n = pro_apply(wrap ? a_nxt[0] : a_cur[(j + 1) & 3], sc_n, sh_n, row_n, k0n);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) pbv[t] = bn[t];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    pav = av_n;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ((BF || PIPE) ? 0 : 4); ++j) {
                 const int k0 = 32 * kb + 8 * j + 4 * h;
                 f32x4 av = a_cur[j];
                 if (PRO) {
@@ -399,7 +480,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
   }   // blocks of rows
 }
 
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false>
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
 static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
@@ -407,7 +488,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
     constexpr size_t lds = lds_main + lds_red;
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
-    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE>;
     if (resident == 0) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -435,7 +516,13 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
 template <int CIN, int NT, int PRO, bool POOL>
 static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
-    if (matrix_precision() == AMPNET_PRECISION_F32) return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+    if (matrix_precision() == AMPNET_PRECISION_F32) {
+        // one-step-ahead operand reads: 2.3 % on the train step, 5.9 % on the eval forward in an interleaved same-box A/B
+        // (scratch/ab_pw_pipe.py); AMPNET_PW_PIPE=0 selects the plain K loop
+        const char *pe = getenv("AMPNET_PW_PIPE");
+        if (pe && pe[0] == '0') return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+        return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true>(a, st);
+    }
     const bool abf = a.a_bf16 != 0, zbf = a.z_bf16 != 0 && a.Z != nullptr;
     if (abf && zbf) return launch_pw_y<CIN, NT, PRO, POOL, true, true, true>(a, st);
     if (abf) return launch_pw_y<CIN, NT, PRO, POOL, true, true, false>(a, st);

@@ -272,20 +272,24 @@ def train_loop_inclusive(enc, att, trainer_mod, B, dev, steps):
     (train_pointnet-attention.py:337-475 end to end)."""
     synth, S = sub("synthetic"), sub("pointNet.amp_step")
     pc, tg, cent, _ = synth.sample_batch(300, B, N_POINTS, max_w=N_WIN)
-    data = (torch.from_numpy(pc), torch.from_numpy(tg), ["f"] * B, torch.from_numpy(cent))
     opt_p, opt_a = trainer_mod.FusedAdam(enc.parameters(), lr=1e-3), trainer_mod.FusedAdam(att.parameters(), lr=1e-3)
     ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]), reduction="mean", ignore_index=-1)
-    np.random.seed(0)
-    for _ in range(2):
-        S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
-    torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N_WIN * N_POINTS / dt, 1),
-            "note": "host batch (pageable) -> upload + ampnet_augment_f32 + fused step + preds/targets download; informational"}
+    out = {"note": "host batch -> upload + ampnet_augment_f32 + fused step + preds/targets download, per train_loop call; informational"}
+    for tag, pin in (("pageable", False), ("pinned", True)):     # pinned = what DataLoader(pin_memory=True) hands to train_loop (amp_train.py)
+        data = (torch.from_numpy(pc), torch.from_numpy(tg), ["f"] * B, torch.from_numpy(cent))
+        if pin:
+            data = (data[0].pin_memory(), data[1].pin_memory(), data[2], data[3])
+        np.random.seed(0)
+        for _ in range(2):
+            S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            S.train_loop(data, opt_p, opt_a, ce, enc, att, None, "segmentation", True, 0, 0)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        out[tag] = {"ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N_WIN * N_POINTS / dt, 1)}
+    return out
 
 
 def self_launch(n_ranks):

@@ -1,0 +1,41 @@
+"""A/B of the pipelined fp32 K loop of pw_gemm (AMPNET_PW_PIPE=1) against the plain form, interleaved in ONE process on ONE box
+(boxes differ by several per cent on MFMA-bound kernels): python3 scratch/ab_pw_pipe.py"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+PKG = "3d-semantic-segmentation-amp-net_amd"
+synth = importlib.import_module(PKG + ".synthetic")
+M = importlib.import_module(PKG + ".pointNet.model.pointnetAtt")
+T = importlib.import_module(PKG + ".trainer")
+S = importlib.import_module(PKG + ".pointNet.amp_step")
+B, W, N = 64, 9, 2048
+enc = M.BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device="cuda")
+att = M.SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, device="cuda")
+tr = T.Trainer(enc, att)
+pc, tg, cent, _ = synth.sample_batch(5, B, N, max_w=W)
+x = torch.from_numpy(pc.transpose(0, 3, 1, 2).copy()).cuda()
+t = torch.from_numpy(tg.transpose(0, 2, 1).copy()).cuda()
+c = torch.from_numpy(cent).cuda()
+
+
+def timed(fn, n):
+    fn(); fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+res = {"0": {"train": [], "fwd": []}, "1": {"train": [], "fwd": []}}
+for rnd in range(4):
+    for v in ("0", "1"):
+        os.environ["AMPNET_PW_PIPE"] = v
+        enc.train(); att.train()
+        res[v]["train"].append(timed(lambda: tr.step(x, t, c), 10))
+        enc.eval(); att.eval()
+        with torch.no_grad():
+            res[v]["fwd"].append(timed(lambda: S.forward_batch(enc, att, x, t, c, None, want_loss=False, want_preds=True), 10))
+for v in ("0", "1"):
+    print(f"AMPNET_PW_PIPE={v}: train step {np.mean(res[v]['train']):.3f} ms (runs {np.round(res[v]['train'], 3)}), eval forward {np.mean(res[v]['fwd']):.3f} ms (runs {np.round(res[v]['fwd'], 3)})")
