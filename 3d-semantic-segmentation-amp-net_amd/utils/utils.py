@@ -175,7 +175,12 @@ def split_kmeans_windows(pc, n_points=2048, max_clusters=9, device="cuda", seed=
 
 def fps(pc, n_samples, device="cuda"):
     """Drop-in for the reference's fps(pc, n_samples): pc [N, D] -> the sampled rows (all D columns) in
-    selection order.  numpy in -> numpy out (like the reference); a GPU tensor in -> GPU tensor out."""
+    selection order.  numpy in -> numpy out (like the reference); a GPU tensor in -> GPU tensor out.
+
+    Deviation: the reference (utils/utils.py:889-933) computes the distances in the dtype of `pc` (float64 for
+    arrays read from LAS files); here they are float32 on the device, whatever the input dtype.  The training
+    pipeline feeds float32 windows, for which the index lists are bit-identical (tests/golden/fps_*.npz); a float64
+    input whose two farthest candidates differ by less than float32 rounding may pick the other one."""
     if isinstance(pc, torch.Tensor):
         t = pc if pc.is_cuda else pc.to(device)
         rows = gather_rows(t.float().unsqueeze(0), fps_indices(t, n_samples).unsqueeze(0))[0]
