@@ -85,3 +85,38 @@ def head_apply(module, pt, bt, gl_rows, lo_rows, centroids, off, mask, B, W, tot
     torch._foreach_add_([module.bn_2.num_batches_tracked, module.bn_3.num_batches_tracked], 1)
     preds = logits.detach().argmax(dim=1) if want_preds else None
     return logits, preds, None
+
+
+class _GruHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, gl, lo, *params):
+        module, pt, bt, off, B, W, total, mx, n_classes, p_drop, seed = meta
+        ws = ops.Workspace()
+        logits, _, _ = ops.gru_head_forward(pt, bt, gl, lo, off, B, W, total, mx, n_classes, True, p_drop, seed, ws)
+        ctx.save_for_backward(gl, lo)
+        ctx.meta = (module, pt, off, B, W, total, mx, n_classes, p_drop, seed, ws)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module, pt, off, B, W, total, mx, n_classes, p_drop, seed, ws = ctx.meta
+        gl, lo = ctx.saved_tensors
+        table = module._param_table()
+        named = dict(module.named_parameters())
+        grads = {n: torch.empty_like(named[n]) for n in table}
+        gt = ops.PointerTable(table, grads, "GRU head gradients")
+        d_lo, d_gl = ops.gru_head_backward(pt, gt, gl, lo, off, B, W, total, mx, n_classes, p_drop, seed,
+                                           dlogits.contiguous().float(), ws, ops.Workspace())
+        ctx.meta = None
+        return (None, d_gl, d_lo) + tuple(grads[n] for n in table)
+
+
+def gru_head_apply(module, pt, bt, gl_rows, lo_rows, off, B, W, total, mx, n_classes, p_drop, seed, want_preds=False):
+    """Grad-mode forward of SegmentationWithGRU: (logits, preds or None, None); a torch loss on the logits back-propagates
+    through _GruHeadFn (the reference's loop, pointNet/rnn/train_pointnetGRU.py:403-433)."""
+    params = _ordered_params(module, module._param_table())
+    logits = _GruHeadFn.apply((module, pt, bt, off, B, W, total, mx, n_classes, p_drop, seed),
+                              gl_rows.contiguous().float(), lo_rows.contiguous().float(), *params)
+    torch._foreach_add_([module.bn_2.num_batches_tracked, module.bn_3.num_batches_tracked], 1)
+    preds = logits.detach().argmax(dim=1) if want_preds else None
+    return logits, preds, None

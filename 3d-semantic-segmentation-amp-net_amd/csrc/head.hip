@@ -14,9 +14,10 @@
 
 namespace ampnet {
 
-HeadShape head_shape(int B, int W, int R, int max_rows, int n_classes, int train)
+HeadShape head_shape(int B, int W, int R, int max_rows, int n_classes, int train, int kind)
 {
     HeadShape s;
+    s.kind = kind;
     s.B = B;
     s.W = W;
     s.Q = B * W;
@@ -60,11 +61,12 @@ void head_carve(const HeadShape &s, void *base, HeadWs &ws)
 {
     Carver c{reinterpret_cast<char *>(base)};
     const size_t Q = (size_t)s.Q, R = (size_t)s.R;
-    ws.tok = c.take<float>(Q * 256);
-    ws.qkv = c.take<float>(Q * 768);
-    ws.probs = c.take<float>((size_t)s.B * HEAD_HEADS * s.W * s.W);
+    const bool gru = s.kind == HEAD_KIND_GRU;
+    ws.tok = c.take<float>(gru ? 0 : Q * 256);
+    ws.qkv = c.take<float>(Q * (gru ? 3 * GRU_H : 768));
+    ws.probs = c.take<float>(gru ? 0 : (size_t)s.B * HEAD_HEADS * s.W * s.W);
     ws.ctx = c.take<float>(Q * 256);
-    ws.g2 = c.take<float>(Q * 256);
+    ws.g2 = c.take<float>(Q * (gru ? GRU_H : 256));
     ws.gbias = c.take<float>(Q * 128);
     ws.z2 = c.take<float>(R * 128);
     ws.z3 = c.take<float>(R * 64);
@@ -89,6 +91,83 @@ using namespace ampnet;
         int rc_ = (x);                    \
         if (rc_ != AMPNET_OK) return rc_; \
     } while (0)
+
+namespace ampnet {
+
+int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, const float *lo, const int32_t *win_off, float dp,
+                    uint32_t seed, const HeadLossArgs &lo_, hipStream_t st)
+{
+    const bool tr = s.train != 0;
+    const int Q = s.Q, B = s.B, total_rows = s.R, max_rows = s.max_rows, n_classes = s.n_classes;
+    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 are stored as bf16 (precision mode 3)
+    if (!tr) {
+        BnFoldItem items[2] = {{p.bn2_w, p.bn2_b, p.bn2_mean, p.bn2_var, ws.bn2.scale, ws.bn2.shift, 128},
+                               {p.bn3_w, p.bn3_b, p.bn3_mean, p.bn3_var, ws.bn3.scale, ws.bn3.shift, 64}};
+        TRY(bn_fold(items, 2, 1e-5f, st));
+    }
+    auto finalize = [&](BnSlot1 &b, const float *gamma, const float *beta) {
+        BnFinalize f;
+        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.chunk_rows = s.chunk_rows;
+        f.win_off = win_off; f.Q = Q; f.chunks = s.chunks; f.n_slots = 1; f.C = b.C;
+        f.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+        f.gamma = gamma; f.beta = beta;
+        f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
+        f.merge_ws = ws.merge;
+        return bn_finalize(f, st);
+    };
+    {   // conv_2: local half + per-window token bias
+        PwGemm g;
+        g.A = lo; g.lda = 64; g.cin = 64;
+        g.W = p.conv2_w; g.ldw = p.conv2_ld;
+        g.bias = ws.gbias; g.bias_win_stride = 128;
+        g.Z = ws.z2; g.ldz = 128; g.cout = 128; g.z_bf16 = zb;
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
+        TRY(pw_gemm(g, st));
+        if (tr) TRY(finalize(ws.bn2, p.bn2_w, p.bn2_b));
+    }
+    {   // conv_3 on dropout(relu(bn_2(z2)))
+        PwGemm g;
+        g.A = ws.z2; g.lda = 128; g.cin = 128; g.a_bf16 = zb;
+        g.W = p.conv3_w; g.ldw = 128; g.bias = p.conv3_b;
+        g.pro_scale = ws.bn2.scale; g.pro_shift = ws.bn2.shift;
+        g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
+        g.Z = ws.z3; g.ldz = 64; g.cout = 64; g.z_bf16 = zb;
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
+        TRY(pw_gemm(g, st));
+        if (tr) TRY(finalize(ws.bn3, p.bn3_w, p.bn3_b));
+    }
+    {
+        HeadOut o;
+        o.z3 = ws.z3; o.scale = ws.bn3.scale; o.shift = ws.bn3.shift;
+        o.W = p.conv4_w; o.bias = p.conv4_b;
+        o.drop_p = dp; o.drop_seed = drop_base(seed, 2);
+        o.R = total_rows; o.P = total_rows / B; o.C = n_classes;
+        o.logits = lo_.logits; o.targets = lo_.targets; o.class_w = lo_.class_w; o.preds = lo_.preds;
+        o.loss_part = lo_.loss_out ? ws.loss_part : nullptr;
+        int blocks = 0;
+        // conv_4 on the matrix cores (the 5 output columns ride in one 32-column MFMA tile), then the row-wise tail
+        PwGemm g;
+        g.A = ws.z3; g.lda = 64; g.cin = 64; g.a_bf16 = zb;
+        g.W = p.conv4_w; g.ldw = 64; g.bias = p.conv4_b;
+        g.pro_scale = ws.bn3.scale; g.pro_shift = ws.bn3.shift;
+        g.drop_p = dp; g.drop_seed = drop_base(seed, 2);
+        g.Z = ws.z4; g.ldz = HEAD_MAX_CLASSES; g.cout = n_classes;
+        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
+        TRY(pw_gemm(g, st));
+        TRY(head_logits(o, ws.z4, HEAD_MAX_CLASSES, &blocks, st));
+        if (lo_.loss_out) TRY(loss_finalize(ws.loss_part, blocks, lo_.loss_out, st));
+    }
+    if (tr) {
+        BnRunItem items[2] = {{ws.bn2.smean, ws.bn2.suvar, p.bn2_mean, p.bn2_var, 128, 1},
+                              {ws.bn3.smean, ws.bn3.suvar, p.bn3_mean, p.bn3_var, 64, 1}};
+        TRY(bn_running_update(items, 2, 0.1f, st));
+    }
+    return AMPNET_OK;
+}
+
+}  // namespace ampnet
 
 extern "C" size_t ampnet_head_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes, int train)
 {
@@ -121,7 +200,6 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     const float dp = tr ? drop_p : 0.f;
     const int Q = s.Q;
 
-    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 are stored as bf16 (precision mode 3)
     TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
     auto tok_gemm = [&](const float *A, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
@@ -137,69 +215,13 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     TRY(tok_gemm(ws.ctx, P[HP_OUTPROJ_W], 256, P[HP_OUTPROJ_B], 256, ws.g2));
     TRY(tok_gemm(ws.g2, P[HP_CONV2_W] + 64, 320, P[HP_CONV2_B], 128, ws.gbias));   // token half of conv_2 + its bias
 
-    if (!tr) {
-        BnFoldItem items[2] = {{P[HP_BN2_W], P[HP_BN2_B], buffers_host[HB_BN2_MEAN], buffers_host[HB_BN2_VAR], ws.bn2.scale, ws.bn2.shift, 128},
-                               {P[HP_BN3_W], P[HP_BN3_B], buffers_host[HB_BN3_MEAN], buffers_host[HB_BN3_VAR], ws.bn3.scale, ws.bn3.shift, 64}};
-        TRY(bn_fold(items, 2, 1e-5f, st));
-    }
-    auto finalize = [&](BnSlot1 &b, int wi, int bi) {
-        BnFinalize f;
-        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.chunk_rows = s.chunk_rows;
-        f.win_off = win_off; f.Q = Q; f.chunks = s.chunks; f.n_slots = 1; f.C = b.C;
-        f.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
-        f.gamma = P[wi]; f.beta = P[bi];
-        f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
-        f.merge_ws = ws.merge;
-        return bn_finalize(f, st);
-    };
-    {   // conv_2: local half + per-window token bias
-        PwGemm g;
-        g.A = lo; g.lda = 64; g.cin = 64;
-        g.W = P[HP_CONV2_W]; g.ldw = 320;
-        g.bias = ws.gbias; g.bias_win_stride = 128;
-        g.Z = ws.z2; g.ldz = 128; g.cout = 128; g.z_bf16 = zb;
-        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
-        TRY(pw_gemm(g, st));
-        if (tr) TRY(finalize(ws.bn2, HP_BN2_W, HP_BN2_B));
-    }
-    {   // conv_3 on dropout(relu(bn_2(z2)))
-        PwGemm g;
-        g.A = ws.z2; g.lda = 128; g.cin = 128; g.a_bf16 = zb;
-        g.W = P[HP_CONV3_W]; g.ldw = 128; g.bias = P[HP_CONV3_B];
-        g.pro_scale = ws.bn2.scale; g.pro_shift = ws.bn2.shift;
-        g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
-        g.Z = ws.z3; g.ldz = 64; g.cout = 64; g.z_bf16 = zb;
-        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
-        TRY(pw_gemm(g, st));
-        if (tr) TRY(finalize(ws.bn3, HP_BN3_W, HP_BN3_B));
-    }
-    {
-        HeadOut o;
-        o.z3 = ws.z3; o.scale = ws.bn3.scale; o.shift = ws.bn3.shift;
-        o.W = P[HP_CONV4_W]; o.bias = P[HP_CONV4_B];
-        o.drop_p = dp; o.drop_seed = drop_base(seed, 2);
-        o.R = total_rows; o.P = total_rows / B; o.C = n_classes;
-        o.logits = logits; o.targets = targets; o.class_w = class_w; o.preds = preds;
-        o.loss_part = loss_out ? ws.loss_part : nullptr;
-        int blocks = 0;
-        // conv_4 on the matrix cores (the 5 output columns ride in one 32-column MFMA tile), then the row-wise tail
-        PwGemm g;
-        g.A = ws.z3; g.lda = 64; g.cin = 64; g.a_bf16 = zb;
-        g.W = P[HP_CONV4_W]; g.ldw = 64; g.bias = P[HP_CONV4_B];
-        g.pro_scale = ws.bn3.scale; g.pro_shift = ws.bn3.shift;
-        g.drop_p = dp; g.drop_seed = drop_base(seed, 2);
-        g.Z = ws.z4; g.ldz = HEAD_MAX_CLASSES; g.cout = n_classes;
-        g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
-        TRY(pw_gemm(g, st));
-        TRY(head_logits(o, ws.z4, HEAD_MAX_CLASSES, &blocks, st));
-        if (loss_out) TRY(loss_finalize(ws.loss_part, blocks, loss_out, st));
-    }
-    if (tr) {
-        BnRunItem items[2] = {{ws.bn2.smean, ws.bn2.suvar, buffers_host[HB_BN2_MEAN], buffers_host[HB_BN2_VAR], 128, 1},
-                              {ws.bn3.smean, ws.bn3.suvar, buffers_host[HB_BN3_MEAN], buffers_host[HB_BN3_VAR], 64, 1}};
-        TRY(bn_running_update(items, 2, 0.1f, st));
-    }
-    return AMPNET_OK;
+    HeadPointParams pp;
+    pp.conv2_w = P[HP_CONV2_W]; pp.conv2_ld = 320;
+    pp.conv3_w = P[HP_CONV3_W]; pp.conv3_b = P[HP_CONV3_B]; pp.conv4_w = P[HP_CONV4_W]; pp.conv4_b = P[HP_CONV4_B];
+    pp.bn2_w = P[HP_BN2_W]; pp.bn2_b = P[HP_BN2_B]; pp.bn3_w = P[HP_BN3_W]; pp.bn3_b = P[HP_BN3_B];
+    pp.bn2_mean = buffers_host[HB_BN2_MEAN]; pp.bn2_var = buffers_host[HB_BN2_VAR];
+    pp.bn3_mean = buffers_host[HB_BN3_MEAN]; pp.bn3_var = buffers_host[HB_BN3_VAR];
+    HeadLossArgs lo_args;
+    lo_args.logits = logits; lo_args.targets = targets; lo_args.class_w = class_w; lo_args.preds = preds; lo_args.loss_out = loss_out;
+    return head_points_fwd(s, ws, pp, lo, win_off, dp, seed, lo_args, st);
 }

@@ -204,17 +204,20 @@ __global__ void mul_inplace_kernel(float *__restrict__ x, const float *__restric
     if (i < n) x[i] *= y[i];
 }
 
-struct HeadBwdWs {
-    float *dy3, *dy2;              // [R,64] [R,128]
-    float *wpart, *dbpart, *dgb;   // [Q * wchunks, 128*128], [Q * wchunks, 128], [Q, 128] gradient of the per-window token bias
-    float *w4part;                 // [blocks, C*64 + C]
-    float *part_a, *part_b;        // [max(Q*chunks, blocks), 128]
-    float *P1[2], *P2[2], *P3[2], *slot_ab[2];   // bn2 (128), bn3 (64)
-    float *d_g2, *d_ctx, *d_qkv, *hid, *slope, *d_hid;
-    int *tot_off;                  // {0, R}
-    size_t bytes;
-};
+}  // namespace
+}  // namespace ampnet
 
+using namespace ampnet;
+
+#define TRY(x)                            \
+    do {                                  \
+        int rc_ = (x);                    \
+        if (rc_ != AMPNET_OK) return rc_; \
+    } while (0)
+
+namespace ampnet {
+
+namespace {
 struct Carver {
     char *base;
     size_t off = 0;
@@ -227,6 +230,8 @@ struct Carver {
         return p;
     }
 };
+
+}  // namespace
 
 void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
 {
@@ -251,26 +256,135 @@ void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
         w.P3[i] = c.take<float>(Cs[i]);
         w.slot_ab[i] = c.take<float>(2 * Cs[i]);
     }
-    w.d_g2 = c.take<float>(Q * 256);
+    const bool gru = s.kind == HEAD_KIND_GRU;
+    w.d_g2 = c.take<float>(Q * (gru ? GRU_H : 256));
     w.d_ctx = c.take<float>(Q * 256);
-    w.d_qkv = c.take<float>(Q * 768);
-    w.hid = c.take<float>(Q * 16);
-    w.slope = c.take<float>(Q * 16);
-    w.d_hid = c.take<float>(Q * 16);
+    w.d_qkv = c.take<float>(Q * (gru ? 3 * GRU_H : 768));
+    w.hid = c.take<float>(Q * (gru ? GRU_H : 16));
+    w.slope = c.take<float>(gru ? 0 : Q * 16);
+    w.d_hid = c.take<float>(gru ? 0 : Q * 16);
     w.tot_off = c.take<int>(2);
     w.bytes = align_up(c.off, 256);
 }
 
-}  // namespace
+
+int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPointParams &p_, const HeadPointGrads &g, const float *lo,
+                    const int32_t *win_off, float drop_p, uint32_t seed, const float *dlogits, float *d_lo, hipStream_t st)
+{
+    const int B = s.B, Q = s.Q, R = s.R, C = s.n_classes, total_rows = s.R, max_rows = s.max_rows;
+    const int blocks = cdiv(R, HB_ROWS);
+    const int wch = cdiv(max_rows, 1024);
+    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 of this forward workspace are bf16 tensors (precision mode 3)
+    TRY(fill_i32_ramp(b.tot_off, 2, R, st));
+    // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
+    {
+        HeadOutBwd o;
+        o.dlogits = dlogits; o.z3 = f.z3; o.z_bf16 = zb;
+        o.scale = f.bn3.scale; o.shift = f.bn3.shift; o.mean = f.bn3.mean; o.invstd = f.bn3.invstd;
+        o.W = p_.conv4_w; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
+        o.R = R; o.P = R / B; o.C = C;
+        o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
+        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
+        TRY(check_launch("head_out_bwd_kernel"));
+        TRY(reduce_windows(b.w4part, blocks, C * 64 + C, 1, C * 64, C * 64, g.conv4_w, C * 64, 0, st));
+        TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, g.conv4_b, C, 0, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = b.tot_off; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
+        fz.uniform_rows = R;
+        fz.gamma = p_.bn3_w; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
+        fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
+        TRY(bn_bwd_finalize(fz, st));
+    }
+    // ---- conv_3: z3 = dropout(relu(bn_2(z2))) W3^T + b3 --------------------------------------------------
+    GradSrc g3;
+    g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1]; g3.z_bf16 = zb;
+    ActSrc a2;
+    a2.z = f.z2; a2.C = 128; a2.z_bf16 = zb; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
+    const char *fenv = getenv("AMPNET_FUSED_BWD");
+    const bool fused = !(fenv && fenv[0] == '0');
+    AMPNET_REQUIRE(!zb || fused, "ampnet_head_bwd_f32: bf16 activation storage needs the fused backward");
+    if (fused) {
+        // one pass over (dy3, z3, z2): weight + bias gradient partials and dy2 with bn_2's backward sums
+        PwBwd p;
+        p.g = g3; p.prev = a2; p.prev_mean = f.bn2.mean; p.prev_invstd = f.bn2.invstd;
+        p.W = p_.conv3_w; p.ldw = 128; p.out = b.dy2; p.dWpart = b.wpart; p.dbpart = b.dbpart;
+        p.part_a = b.part_a; p.part_b = b.part_b;
+        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
+        p.blocks_per_slot = pw_bwd_blocks(Q, 1, max_rows);
+        const int nblk = p.blocks_per_slot;
+        TRY(pw_bwd_fused(p, st));
+        TRY(reduce_windows(b.wpart, nblk, 64 * 128, 64, 128, 128, g.conv3_w, 128, 0, st));
+        TRY(reduce_windows(b.dbpart, nblk, 64, 1, 64, 64, g.conv3_b, 64, 0, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = 1; fz.part_Q = nblk; fz.n_slots = 1; fz.C = 128;
+        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+        fz.gamma = p_.bn2_w; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
+        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
+        TRY(bn_bwd_finalize(fz, st));
+    } else {
+        PwWgrad w;
+        w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
+        TRY(pw_wgrad(w, st));
+        TRY(reduce_windows(b.wpart, Q * wch, 64 * 128, 64, 128, 128, g.conv3_w, 128, 0, st));
+        TRY(reduce_windows(b.dbpart, Q * wch, 64, 1, 64, 64, g.conv3_b, 64, 0, st));
+        PwDgrad d;
+        d.g = g3; d.W = p_.conv3_w; d.ldw = 128; d.prev = a2; d.prev_mean = f.bn2.mean; d.prev_invstd = f.bn2.invstd;
+        d.out = b.dy2; d.cp = 128; d.part_a = b.part_a; d.part_b = b.part_b;
+        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
+        TRY(pw_dgrad(d, st));
+        BnBwdFinalize fz;
+        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = s.chunks; fz.n_slots = 1; fz.C = 128;
+        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+        fz.gamma = p_.bn2_w; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
+        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
+        TRY(bn_bwd_finalize(fz, st));
+    }
+    // ---- conv_2: z2 = lo W2[:, :64]^T + (token W2[:, 64:]^T + b2)[window] ------------------------------------
+    GradSrc g2;
+    g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0]; g2.z_bf16 = zb;
+    // fused form: every workgroup stays inside one window, so its column sums of g2 are a per-window partial of the
+    // token-bias gradient
+    const int cpw = cdiv(max_rows, pw_bwd_item_rows());
+    int ipb = cpw < 4 ? cpw : 4;
+    while (cpw % ipb) --ipb;
+    const int bpw = cpw / ipb;                                  // workgroups per window
+    AMPNET_REQUIRE(!zb || bpw <= wch, "ampnet_head_bwd_f32: bf16 activation storage needs the fused conv_2 backward");
+    if (fused && bpw <= wch) {
+        PwBwd p;
+        p.g = g2; p.prev.z = lo; p.prev.C = 64;
+        p.W = p_.conv2_w; p.ldw = p_.conv2_ld; p.out = d_lo; p.dWpart = b.wpart; p.dbpart = b.dbpart;
+        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
+        p.items_per_block = ipb; p.blocks_per_slot = Q * bpw;
+        TRY(pw_bwd_fused(p, st));
+        TRY(reduce_windows(b.wpart, Q * bpw, 128 * 64, 128, 64, 64, g.conv2_w, g.conv2_ld, 0, st));
+        TRY(reduce_windows(b.dbpart, bpw, 128, Q, 128, bpw * 128, b.dgb, 128, 0, st));
+        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, g.conv2_b, 128, 0, st));
+    } else {
+        ActSrc yl;
+        yl.z = lo; yl.C = 64;
+        PwWgrad w;
+        w.x = g2; w.y = yl; w.dWpart = b.wpart; w.ldp = 64; w.dbpart = b.dbpart;      // dbpart[q] = d(token bias of window q)
+        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
+        TRY(pw_wgrad(w, st));
+        TRY(reduce_windows(b.wpart, Q * wch, 128 * 64, 128, 64, 64, g.conv2_w, g.conv2_ld, 0, st));
+        // per-window sums of the chunk partials = gradient of the per-window token bias; their sum = conv_2.bias gradient
+        TRY(reduce_windows(b.dbpart, wch, 128, Q, 128, wch * 128, b.dgb, 128, 0, st));
+        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, g.conv2_b, 128, 0, st));
+        PwDgrad d;
+        d.g = g2; d.W = p_.conv2_w; d.ldw = p_.conv2_ld; d.out = d_lo; d.cp = 64;
+        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
+        TRY(pw_dgrad(d, st));
+    }
+    // ---- BatchNorm weight / bias gradients ---------------------------------------------------------------------------
+    {
+        BnGradItem items[2] = {{b.slot_ab[0], g.bn2_w, g.bn2_b, 128, 1}, {b.slot_ab[1], g.bn3_w, g.bn3_b, 64, 1}};
+        TRY(bn_param_grads(items, 2, st));
+    }
+    return AMPNET_OK;
+}
+
 }  // namespace ampnet
-
-using namespace ampnet;
-
-#define TRY(x)                            \
-    do {                                  \
-        int rc_ = (x);                    \
-        if (rc_ != AMPNET_OK) return rc_; \
-    } while (0)
 
 extern "C" size_t ampnet_head_bwd_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes)
 {
@@ -300,112 +414,16 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     if (b.bytes > bwd_workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_head_bwd_f32: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.bytes);
     const float *const *P = params_host;
     float *const *G = grads_host;
-    const int Q = s.Q, R = total_rows, C = n_classes;
-    const int blocks = cdiv(R, HB_ROWS);
-    const int wch = cdiv(max_rows, 1024);
-
-    const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 of this forward workspace are bf16 tensors (precision mode 3)
-    TRY(fill_i32_ramp(b.tot_off, 2, R, st));
-    // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
-    {
-        HeadOutBwd o;
-        o.dlogits = dlogits; o.z3 = f.z3; o.z_bf16 = zb;
-        o.scale = f.bn3.scale; o.shift = f.bn3.shift; o.mean = f.bn3.mean; o.invstd = f.bn3.invstd;
-        o.W = P[HP_CONV4_W]; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
-        o.R = R; o.P = R / B; o.C = C;
-        o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
-        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
-        TRY(check_launch("head_out_bwd_kernel"));
-        TRY(reduce_windows(b.w4part, blocks, C * 64 + C, 1, C * 64, C * 64, G[HP_CONV4_W], C * 64, 0, st));
-        TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, G[HP_CONV4_B], C, 0, st));
-        BnBwdFinalize fz;
-        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = b.tot_off; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
-        fz.uniform_rows = R;
-        fz.gamma = P[HP_BN3_W]; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
-        fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
-        TRY(bn_bwd_finalize(fz, st));
-    }
-    // ---- conv_3: z3 = dropout(relu(bn_2(z2))) W3^T + b3 --------------------------------------------------
-    GradSrc g3;
-    g3.dy = b.dy3; g3.z = f.z3; g3.C = 64; g3.P1 = b.P1[1]; g3.P2 = b.P2[1]; g3.P3 = b.P3[1]; g3.z_bf16 = zb;
-    ActSrc a2;
-    a2.z = f.z2; a2.C = 128; a2.z_bf16 = zb; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
-    const char *fenv = getenv("AMPNET_FUSED_BWD");
-    const bool fused = !(fenv && fenv[0] == '0');
-    AMPNET_REQUIRE(!zb || fused, "ampnet_head_bwd_f32: bf16 activation storage needs the fused backward");
-    if (fused) {
-        // one pass over (dy3, z3, z2): weight + bias gradient partials and dy2 with bn_2's backward sums
-        PwBwd p;
-        p.g = g3; p.prev = a2; p.prev_mean = f.bn2.mean; p.prev_invstd = f.bn2.invstd;
-        p.W = P[HP_CONV3_W]; p.ldw = 128; p.out = b.dy2; p.dWpart = b.wpart; p.dbpart = b.dbpart;
-        p.part_a = b.part_a; p.part_b = b.part_b;
-        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
-        p.blocks_per_slot = pw_bwd_blocks(Q, 1, max_rows);
-        const int nblk = p.blocks_per_slot;
-        TRY(pw_bwd_fused(p, st));
-        TRY(reduce_windows(b.wpart, nblk, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
-        TRY(reduce_windows(b.dbpart, nblk, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
-        BnBwdFinalize fz;
-        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = 1; fz.part_Q = nblk; fz.n_slots = 1; fz.C = 128;
-        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
-        fz.gamma = P[HP_BN2_W]; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
-        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
-        TRY(bn_bwd_finalize(fz, st));
-    } else {
-        PwWgrad w;
-        w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
-        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
-        TRY(pw_wgrad(w, st));
-        TRY(reduce_windows(b.wpart, Q * wch, 64 * 128, 64, 128, 128, G[HP_CONV3_W], 128, 0, st));
-        TRY(reduce_windows(b.dbpart, Q * wch, 64, 1, 64, 64, G[HP_CONV3_B], 64, 0, st));
-        PwDgrad d;
-        d.g = g3; d.W = P[HP_CONV3_W]; d.ldw = 128; d.prev = a2; d.prev_mean = f.bn2.mean; d.prev_invstd = f.bn2.invstd;
-        d.out = b.dy2; d.cp = 128; d.part_a = b.part_a; d.part_b = b.part_b;
-        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
-        TRY(pw_dgrad(d, st));
-        BnBwdFinalize fz;
-        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = s.chunks; fz.n_slots = 1; fz.C = 128;
-        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
-        fz.gamma = P[HP_BN2_W]; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
-        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
-        TRY(bn_bwd_finalize(fz, st));
-    }
-    // ---- conv_2: z2 = lo W2[:, :64]^T + (token W2[:, 64:]^T + b2)[window] ------------------------------------
-    GradSrc g2;
-    g2.dy = b.dy2; g2.z = f.z2; g2.C = 128; g2.P1 = b.P1[0]; g2.P2 = b.P2[0]; g2.P3 = b.P3[0]; g2.z_bf16 = zb;
-    // fused form: every workgroup stays inside one window, so its column sums of g2 are a per-window partial of the
-    // token-bias gradient
-    const int cpw = cdiv(max_rows, pw_bwd_item_rows());
-    int ipb = cpw < 4 ? cpw : 4;
-    while (cpw % ipb) --ipb;
-    const int bpw = cpw / ipb;                                  // workgroups per window
-    AMPNET_REQUIRE(!zb || bpw <= wch, "ampnet_head_bwd_f32: bf16 activation storage needs the fused conv_2 backward");
-    if (fused && bpw <= wch) {
-        PwBwd p;
-        p.g = g2; p.prev.z = lo; p.prev.C = 64;
-        p.W = P[HP_CONV2_W]; p.ldw = 320; p.out = d_lo; p.dWpart = b.wpart; p.dbpart = b.dbpart;
-        p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
-        p.items_per_block = ipb; p.blocks_per_slot = Q * bpw;
-        TRY(pw_bwd_fused(p, st));
-        TRY(reduce_windows(b.wpart, Q * bpw, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
-        TRY(reduce_windows(b.dbpart, bpw, 128, Q, 128, bpw * 128, b.dgb, 128, 0, st));
-        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
-    } else {
-        ActSrc yl;
-        yl.z = lo; yl.C = 64;
-        PwWgrad w;
-        w.x = g2; w.y = yl; w.dWpart = b.wpart; w.ldp = 64; w.dbpart = b.dbpart;      // dbpart[q] = d(token bias of window q)
-        w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
-        TRY(pw_wgrad(w, st));
-        TRY(reduce_windows(b.wpart, Q * wch, 128 * 64, 128, 64, 64, G[HP_CONV2_W], 320, 0, st));
-        // per-window sums of the chunk partials = gradient of the per-window token bias; their sum = conv_2.bias gradient
-        TRY(reduce_windows(b.dbpart, wch, 128, Q, 128, wch * 128, b.dgb, 128, 0, st));
-        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, G[HP_CONV2_B], 128, 0, st));
-        PwDgrad d;
-        d.g = g2; d.W = P[HP_CONV2_W]; d.ldw = 320; d.out = d_lo; d.cp = 64;
-        d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
-        TRY(pw_dgrad(d, st));
-    }
+    const int Q = s.Q;
+    HeadPointParams pp;
+    pp.conv2_w = P[HP_CONV2_W]; pp.conv2_ld = 320;
+    pp.conv3_w = P[HP_CONV3_W]; pp.conv3_b = P[HP_CONV3_B]; pp.conv4_w = P[HP_CONV4_W]; pp.conv4_b = P[HP_CONV4_B];
+    pp.bn2_w = P[HP_BN2_W]; pp.bn2_b = P[HP_BN2_B]; pp.bn3_w = P[HP_BN3_W]; pp.bn3_b = P[HP_BN3_B];
+    HeadPointGrads pg;
+    pg.conv2_w = G[HP_CONV2_W]; pg.conv2_ld = 320; pg.conv2_b = G[HP_CONV2_B];
+    pg.conv3_w = G[HP_CONV3_W]; pg.conv3_b = G[HP_CONV3_B]; pg.conv4_w = G[HP_CONV4_W]; pg.conv4_b = G[HP_CONV4_B];
+    pg.bn2_w = G[HP_BN2_W]; pg.bn2_b = G[HP_BN2_B]; pg.bn3_w = G[HP_BN3_W]; pg.bn3_b = G[HP_BN3_B];
+    TRY(head_points_bwd(s, f, b, pp, pg, lo, win_off, drop_p, seed, dlogits, d_lo, st));
     // ---- token path: gbias = g2tok W2[:, 64:]^T + b2 ; g2tok = ctx Wo^T + bo ; qkv = tok Wi^T + bi -------------
     const float *d_gbias = b.dgb;                                                           // [Q, 128]
     TRY(sgemm_linear_bwd(Q, 128, 256, d_gbias, 128, f.g2, 256, P[HP_CONV2_W] + 64, 320, G[HP_CONV2_W] + 64, 320, b.d_g2, 256, st));
@@ -425,10 +443,5 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     TRY(check_launch("mul_inplace_kernel"));
     TRY(sgemm_small(1, 0, 16, 2, Q, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, 0, st));
     TRY(colsum(b.d_hid, Q, 16, G[HP_FC1_B], st));
-    // ---- BatchNorm weight / bias gradients ---------------------------------------------------------------------------
-    {
-        BnGradItem items[2] = {{b.slot_ab[0], G[HP_BN2_W], G[HP_BN2_B], 128, 1}, {b.slot_ab[1], G[HP_BN3_W], G[HP_BN3_B], 64, 1}};
-        TRY(bn_param_grads(items, 2, st));
-    }
     return AMPNET_OK;
 }

@@ -134,6 +134,64 @@ def head_forward(head_params, head_buffers, gl, lo, centroids, win_off, mask, B,
     return logits, preds, loss
 
 
+def gru_head_forward(head_params, head_buffers, gl, lo, win_off, B, W, total_rows, max_rows, n_classes, train, drop_p, seed, ws,
+                     targets=None, class_w=None, want_preds=False):
+    """SegmentationWithGRU on the HIP path: gl [B*W, 256] (row b*W+w = global_seq[b, w]), lo [total_rows, 64]
+    -> (logits [B, C, P], preds [B, P] int64 or None, loss [2] (ce, sum of weights) or None).
+    See include/ampnet_hip.h: ampnet_gru_head_fwd_f32."""
+    for t, name in ((gl, "gl"), (lo, "lo")):
+        _lib.require_gpu(t, name)
+        if t.dtype != torch.float32:
+            raise _lib.AmpnetError(f"gru_head_forward: {name} must be float32")
+    if tuple(gl.shape) != (B * W, P.GLOBAL_DIM) or tuple(lo.shape) != (total_rows, P.LOCAL_DIM):
+        raise _lib.AmpnetError(f"gru_head_forward: shapes gl {tuple(gl.shape)} lo {tuple(lo.shape)} do not match B={B} W={W} rows={total_rows}")
+    dev = gl.device
+    gl, lo = gl.contiguous(), lo.contiguous()
+    Pp = total_rows // B
+    L = _lib.lib()
+    L.ampnet_gru_head_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_gru_head_workspace_bytes(B, W, total_rows, max_rows, n_classes, int(train))
+    buf = ws.get(need, dev)
+    logits = torch.empty((B, n_classes, Pp), dtype=torch.float32, device=dev)
+    preds = torch.empty((B, Pp), dtype=torch.int64, device=dev) if want_preds else None
+    loss, tg, cw = None, None, None
+    if targets is not None:
+        tg = targets.to(device=dev, dtype=torch.int64).contiguous()
+        if tuple(tg.shape) != (B, Pp):
+            raise _lib.AmpnetError(f"gru_head_forward: targets {tuple(tg.shape)} != [B={B}, P={Pp}]")
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        cw = (class_w if class_w is not None else torch.ones(n_classes)).to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        rc = L.ampnet_gru_head_fwd_f32(head_params.arr, head_buffers.arr, _lib.ptr(gl), _lib.ptr(lo), _lib.ptr(win_off), B, W,
+                                       total_rows, max_rows, n_classes, int(train), ctypes.c_float(drop_p),
+                                       ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(logits), _lib.ptr(tg), _lib.ptr(cw), _lib.ptr(preds),
+                                       _lib.ptr(loss), _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_gru_head_fwd_f32")
+    return logits, preds, loss
+
+
+def gru_head_backward(head_params, grad_table, gl, lo, win_off, B, W, total_rows, max_rows, n_classes, drop_p, seed, dlogits, fwd_ws, bwd_ws):
+    """Backward of a train-mode gru_head_forward (same arguments, fwd_ws untouched since) -> (d_lo [rows, 64], d_gl [B*W, 256])."""
+    dev = lo.device
+    L = _lib.lib()
+    L.ampnet_gru_head_bwd_workspace_bytes.restype = ctypes.c_size_t
+    need = L.ampnet_gru_head_bwd_workspace_bytes(B, W, total_rows, max_rows, n_classes)
+    buf = bwd_ws.get(need, dev)
+    fbuf = fwd_ws.buf
+    Pp = total_rows // B
+    if tuple(dlogits.shape) != (B, n_classes, Pp) or dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
+        raise _lib.AmpnetError(f"gru_head_backward: dlogits must be contiguous float32 [B, C, P], got {tuple(dlogits.shape)}")
+    d_lo = torch.empty((total_rows, 64), dtype=torch.float32, device=dev)
+    d_gl = torch.empty((B * W, P.GLOBAL_DIM), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.ampnet_gru_head_bwd_f32(head_params.arr, grad_table.arr, _lib.ptr(gl.contiguous()), _lib.ptr(lo.contiguous()), _lib.ptr(win_off),
+                                       B, W, total_rows, max_rows, n_classes, ctypes.c_float(drop_p), ctypes.c_uint32(seed & 0xFFFFFFFF),
+                                       _lib.ptr(dlogits), _lib.ptr(d_lo), _lib.ptr(d_gl), _lib.ptr(fbuf), ctypes.c_size_t(fbuf.numel()),
+                                       _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_gru_head_bwd_f32")
+    return d_lo, d_gl
+
+
 def reg_loss(feat_T, keep_G=False):
     """|| I - F F^T ||_F over the stack feat_T [n, 64, 64] -> device scalar tensor [1] (and G when keep_G)."""
     _lib.require_gpu(feat_T, "feat_T")

@@ -85,6 +85,20 @@ HEAD_PARAMS = OrderedDict([
 
 HEAD_BUFFERS = OrderedDict(_bn_bufs("bn_2.", 128) + _bn_bufs("bn_3.", 64))
 
+# SegmentationWithGRU (pointnetAtt.py:214-230; HIDDEN_SIZE = 64, pointNet/rnn/train_pointnetGRU.py:27-28): state_dict order
+GRU_HIDDEN = 64
+GRU_HEAD_PARAMS = OrderedDict([
+    ("gru_global.weight_ih_l0", (3 * GRU_HIDDEN, GLOBAL_DIM)),
+    ("gru_global.weight_hh_l0", (3 * GRU_HIDDEN, GRU_HIDDEN)),
+    ("gru_global.bias_ih_l0", (3 * GRU_HIDDEN,)),
+    ("gru_global.bias_hh_l0", (3 * GRU_HIDDEN,)),
+    ("conv_2.weight", (128, LOCAL_DIM + GRU_HIDDEN, 1)), ("conv_2.bias", (128,)),
+    ("conv_3.weight", (64, 128, 1)), ("conv_3.bias", (64,)),
+    ("conv_4.weight", (NUM_CLASSES, 64, 1)), ("conv_4.bias", (NUM_CLASSES,)),
+    ("bn_2.weight", (128,)), ("bn_2.bias", (128,)),
+    ("bn_3.weight", (64,)), ("bn_3.bias", (64,)),
+])
+
 
 def numel(shape):
     n = 1

@@ -2,7 +2,7 @@
 
 Same class names, constructor arguments, forward signatures, return values and `state_dict` keys as the
 reference's pointNet/model/pointnetAtt.py (TransformationNet :7-47, BasePointNet :50-112,
-SegmentationWithAttention :154-209), so reference checkpoints load and the reference's train/test scripts
+SegmentationWithAttention :154-209, SegmentationWithGRU :212-258), so reference checkpoints load and the reference's train/test scripts
 run unchanged on top of them.  The modules own ordinary nn.Parameters / buffers (as holders: their own
 `forward` is never used); every forward goes through the C ABI (ops.encoder_forward / ops.head_forward).
 There is no CPU or torch fallback: on a CPU tensor the call raises.
@@ -240,3 +240,103 @@ class SegmentationWithAttention(nn.Module):
         lo_rows = lo_feats.reshape(-1, lo_feats.shape[2])
         logits, _, _ = self.forward_rows(gl_rows, lo_rows, centroids, np_cluster, attn_mask)
         return logits, 0
+
+
+class _GRU(nn.Module):
+    """Holder with nn.GRU(input, hidden, num_layers=1)'s parameter names, shapes and U(-1/sqrt(H), 1/sqrt(H)) initialisation."""
+
+    def __init__(self, cin, hidden, device):
+        super().__init__()
+        k = 1.0 / hidden ** 0.5
+        self.weight_ih_l0 = nn.Parameter(torch.empty(3 * hidden, cin, device=device).uniform_(-k, k))
+        self.weight_hh_l0 = nn.Parameter(torch.empty(3 * hidden, hidden, device=device).uniform_(-k, k))
+        self.bias_ih_l0 = nn.Parameter(torch.empty(3 * hidden, device=device).uniform_(-k, k))
+        self.bias_hh_l0 = nn.Parameter(torch.empty(3 * hidden, device=device).uniform_(-k, k))
+
+
+class SegmentationWithGRU(nn.Module):
+    """The GRU variant of the sequence model (pointnetAtt.py:212-258): nn.GRU(256 -> 64, batch_first, h0 = 0) over the
+    window tokens, hidden state of step w broadcast over the points of window w, then conv_2 / bn_2 / conv_3 / bn_3 / conv_4 with
+    Dropout(0.3) twice.  Runs through ampnet_gru_head_fwd_f32 / _bwd_f32 (csrc/gru_head.hip)."""
+    head_kind = "gru"
+
+    def __init__(self, num_classes, global_feat_size, hidden_size, device):
+        super().__init__()
+        if global_feat_size != P.GLOBAL_DIM or hidden_size != P.GRU_HIDDEN or not (1 <= num_classes <= 8):
+            raise NotImplementedError("the HIP GRU head is built for global_feat_size=256, hidden_size=64, num_classes<=8 "
+                                      "(pointNet/rnn/train_pointnetGRU.py:27-28,128)")
+        self.hidden_size = hidden_size
+        self.device = device
+        self.num_classes = num_classes
+        self.p_drop = 0.3                                   # nn.Dropout(0.3), pointnetAtt.py:225
+        self.gru_global = _GRU(global_feat_size, hidden_size, device)
+        self.conv_2 = _Conv(64 + 64, 128, True, device)
+        self.conv_3 = _Conv(128, 64, True, device)
+        self.conv_4 = _Conv(64, num_classes, True, device)
+        self.bn_2 = _BN(128, device)
+        self.bn_3 = _BN(64, device)
+        self._cache = _TableCache()
+        self._ws = ops.Workspace()
+        self._step = 0
+        self.seed = 0x6A09E667
+
+    def _param_table(self):
+        from collections import OrderedDict
+        table = OrderedDict(P.GRU_HEAD_PARAMS)
+        table["conv_4.weight"] = (self.num_classes, 64, 1)
+        table["conv_4.bias"] = (self.num_classes,)
+        return table
+
+    def _tables(self):
+        return self._cache.get(self, self._param_table(), P.HEAD_BUFFERS, "SegmentationWithGRU")
+
+    def next_seed(self):
+        seed = (self.seed + 0x632BE5AB * self._step) & 0xFFFFFFFF
+        if self.training:
+            self._step += 1
+        return seed
+
+    def forward_rows(self, gl_rows, lo_rows, np_cluster, B, targets=None, class_w=None, want_preds=False):
+        """gl_rows [B*W, 256] (row b*W+w), lo_rows [B*P, 64], np_cluster: the W window sizes of a sample
+        -> (logits [B, C, P], preds or None, loss or None)."""
+        W = len(np_cluster)
+        sizes = [int(n) for n in np_cluster] * B
+        off, total, mx = ops.window_offsets(sizes, lo_rows.device)
+        pt, bt = self._tables()
+        train = self.training
+        seed = self.next_seed()
+        if train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ...autograd import gru_head_apply
+            return gru_head_apply(self, pt, bt, gl_rows, lo_rows, off, B, W, total, mx, self.num_classes, self.p_drop, seed, want_preds)
+        out = ops.gru_head_forward(pt, bt, gl_rows.contiguous().float(), lo_rows.contiguous().float(), off, B, W, total, mx, self.num_classes,
+                                   train, self.p_drop, seed, self._ws, targets=targets, class_w=class_w, want_preds=want_preds)
+        if train:
+            torch._foreach_add_([self.bn_2.num_batches_tracked, self.bn_3.num_batches_tracked], 1)
+        return out
+
+    def forward(self, global_seq, local_feats, np_cluster):
+        """Reference signature (pointnetAtt.py:232-250): global_seq [B, W, 256], local_feats [B, P, 64], np_cluster list of W sizes
+        -> logits [B, C, P]."""
+        B, W = global_seq.shape[0], global_seq.shape[1]
+        logits, _, _ = self.forward_rows(global_seq.reshape(B * W, -1), local_feats.reshape(-1, local_feats.shape[2]), np_cluster, B)
+        return logits
+
+    def initHidden(self, x):
+        return torch.zeros(1, x.shape[0], self.hidden_size, device=x.device)
+
+
+class ClassificationFromGRU(nn.Module):
+    """Parameter-compatible holder of pointnetAtt.py:261-279.  The reference's forward reads self.embed_dim, which its __init__ never
+    sets, and no reference script reaches it (train_pointnetGRU.py:405-407 leaves the classification branch without logits): calling it
+    raises AttributeError there; here it raises with the reason."""
+
+    def __init__(self, num_classes=2, dropout=0.3, num_w=5, embed_dim=256, device='cuda'):
+        super().__init__()
+        self.conv_1 = _Conv(num_w, 1, True, device)
+        self.fc_2 = _Linear(embed_dim, 128, True, device)
+        self.fc_3 = _Linear(128, num_classes, True, device)
+        self.bn_2 = _BN(128, device)
+
+    def forward(self, x):
+        raise AttributeError("'ClassificationFromGRU' object has no attribute 'embed_dim' (the reference's forward fails the same way, "
+                             "pointnetAtt.py:274; the classification task is not runnable in the reference)")

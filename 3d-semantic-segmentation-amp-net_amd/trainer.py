@@ -117,7 +117,7 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     B, W, N, _ = xd.shape
     targets_pc = torch.as_tensor(t).reshape(B, W * N)
     tgd = targets_pc.to(dev, non_blocking=True)
-    cent = torch.as_tensor(centroids).to(dev).float().contiguous()
+    cent = torch.as_tensor(centroids).to(dev).float().contiguous() if centroids is not None else None
     Q, rows = B * W, B * W * N
     eg = _store(pointnet, P.ENC_PARAMS)
     hg = _store(att_net, att_net._param_table())
@@ -128,11 +128,18 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     # ---- forward ----
     local, glob, feat_T, _ = ops.encoder_forward(ept, ebt, xr, off, Q, total, mx, W, True, pointnet._ws)
     pointnet._bump_batches(W)
-    mask = (tgd.view(B, -1, W) == -1).all(dim=1)                    # the reference's literal mask (amp_step.forward_batch)
+    gru = getattr(att_net, "head_kind", "attention") == "gru"      # SegmentationWithGRU: no centroids, no key-padding mask
     seed = (att_net.seed + 0x632BE5AB * att_net._step) & 0xFFFFFFFF
     att_net._step += 1
-    logits, preds, loss2 = ops.head_forward(hpt, hbt, glob, local, cent, off, mask, B, W, total, mx, att_net.num_classes, True,
-                                            att_net.p_drop, seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
+    if gru:
+        if class_w is None:
+            class_w = torch.ones(att_net.num_classes, dtype=torch.float32, device=dev)
+        logits, preds, loss2 = ops.gru_head_forward(hpt, hbt, glob, local, off, B, W, total, mx, att_net.num_classes, True, att_net.p_drop,
+                                                    seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
+    else:
+        mask = (tgd.view(B, -1, W) == -1).all(dim=1)                # the reference's literal mask (amp_step.forward_batch)
+        logits, preds, loss2 = ops.head_forward(hpt, hbt, glob, local, cent, off, mask, B, W, total, mx, att_net.num_classes, True,
+                                                att_net.p_drop, seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
     torch._foreach_add_([att_net.bn_2.num_batches_tracked, att_net.bn_3.num_batches_tracked], 1)
     feat_last = feat_T[-B:]
     reg, G = ops.reg_loss(feat_last, keep_G=True)
@@ -140,8 +147,12 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     if not hasattr(att_net, "_bws"):
         att_net._bws, pointnet._bws = ops.Workspace(), ops.Workspace()
     dlog = ops.ce_backward(logits, tgd, class_w, loss2)
-    d_lo, d_gl = ops.head_backward(hpt, hg.table, local, cent, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
-                                   dlog, att_net._ws, att_net._bws)
+    if gru:
+        d_lo, d_gl = ops.gru_head_backward(hpt, hg.table, glob, local, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
+                                           dlog, att_net._ws, att_net._bws)
+    else:
+        d_lo, d_gl = ops.head_backward(hpt, hg.table, local, cent, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
+                                       dlog, att_net._ws, att_net._bws)
     d_ft = torch.zeros_like(feat_T)
     ops.reg_loss_backward(feat_last, G, reg, reg_weight, d_ft[-B:])
     ops.encoder_backward(ept, eg.table, xr, off, Q, total, mx, W, local, feat_T, d_lo, d_gl, d_ft, pointnet._ws, pointnet._bws)

@@ -158,6 +158,29 @@ int ampnet_head_bwd_f32(const float *const *params_host, float *const *grads_hos
                         void *fwd_workspace, size_t fwd_workspace_bytes, void *bwd_workspace,
                         size_t bwd_workspace_bytes, void *stream);
 
+/* ---- f4: the GRU variant of the sequence model ---------------------------------------------------------------
+ * replaces SegmentationWithGRU.forward (pointNet/model/pointnetAtt.py:212-258: nn.GRU(256 -> 64, batch_first, h0 = 0) over the W window
+ * tokens of a sample, the hidden state of step w repeated over the points of window w, cat with the local features, conv_2 / bn_2 /
+ * conv_3 / bn_3 / conv_4 with two dropouts) as pointNet/rnn/train_pointnetGRU.py:335-441 drives it; the repeat + cat is never built.
+ *   params_host  [14] device pointers in state_dict order: gru_global.weight_ih_l0 [192,256], weight_hh_l0 [192,64], bias_ih_l0 [192],
+ *                bias_hh_l0 [192], conv_2.weight [128,128], conv_2.bias, conv_3.weight [64,128], conv_3.bias, conv_4.weight [C,64],
+ *                conv_4.bias, bn_2.weight, bn_2.bias, bn_3.weight, bn_3.bias
+ *   buffers_host [4]  bn_2.running_mean, bn_2.running_var, bn_3.running_mean, bn_3.running_var (updated in train mode)
+ *   gl [B * W, 256] window tokens (row b * W + w = global_seq[b, w, :]); lo, win_off, logits, targets, class_w, preds, loss_out,
+ *   train, drop_p, seed: as ampnet_head_fwd_f32.  There is no key-padding mask: the reference runs the GRU over every window.   */
+size_t ampnet_gru_head_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes, int train);
+int ampnet_gru_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl, const float *lo,
+                            const int32_t *win_off, int B, int W, int total_rows, int max_rows, int n_classes, int train, float drop_p,
+                            uint32_t seed, float *logits, const long long *targets, const float *class_w, long long *preds,
+                            float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+/* autograd backward of the above given dlogits [B, n_classes, P] (must follow a train-mode forward with the same arguments and an
+ * untouched fwd_workspace): grads_host [14] are WRITTEN; d_lo [total_rows, 64], d_gl [B * W, 256].                                */
+size_t ampnet_gru_head_bwd_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes);
+int ampnet_gru_head_bwd_f32(const float *const *params_host, float *const *grads_host, const float *gl, const float *lo,
+                            const int32_t *win_off, int B, int W, int total_rows, int max_rows, int n_classes, float drop_p, uint32_t seed,
+                            const float *dlogits, float *d_lo, float *d_gl, void *fwd_workspace, size_t fwd_workspace_bytes,
+                            void *bwd_workspace, size_t bwd_workspace_bytes, void *stream);
+
 /* ---- a6: loss recipe (train_pointnet-attention.py:138,445,463-467) ------------------------------------
  * reg = || I - F F^T ||_F over the whole stack feat_T [n, 64, 64] (torch.norm of a 3-D tensor = Frobenius over
  * all elements).  G [n, 64, 64] (optional) receives I - F F^T for the backward; part [n] is scratch.

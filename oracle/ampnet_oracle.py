@@ -165,6 +165,60 @@ def forward_windows(enc_p, enc_b, head_p, head_b, pc, targets, centroids, train_
     return logits, targets_pc, t_feat, mask
 
 
+def gru_cell_sequence(p, x):
+    """nn.GRU(256 -> H, num_layers=1, batch_first=True) with h0 = 0 (pointnetAtt.py:219,234-235; gate order r, z, n as torch
+    documents it): x [B, L, 256] -> all hidden states [B, L, H]."""
+    wih, whh = p["gru_global.weight_ih_l0"], p["gru_global.weight_hh_l0"]
+    bih, bhh = p["gru_global.bias_ih_l0"], p["gru_global.bias_hh_l0"]
+    B, L, _ = x.shape
+    H = whh.shape[1]
+    h = torch.zeros(B, H, dtype=x.dtype)
+    out = []
+    for t in range(L):
+        gi = x[:, t] @ wih.t() + bih
+        gh = h @ whh.t() + bhh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1.0 - z) * n + z * h
+        out.append(h)
+    return torch.stack(out, dim=1)
+
+
+def gru_head(p, bufs, global_seq, lo, np_cluster, train, drop_p=0.0, drop_masks=None):
+    """SegmentationWithGRU.forward (pointnetAtt.py:232-250): global_seq [B, W, 256], lo [B, sum(np_cluster), 64]
+    -> logits [B, C, sum(np_cluster)].  drop_masks: None or dict with keep-masks 'd2' [B, 128, P], 'd3' [B, 64, P]."""
+    B, W, _ = global_seq.shape
+    hs = gru_cell_sequence(p, global_seq)                       # [B, W, H]
+    rep = torch.cat([hs[:, i].unsqueeze(1).expand(B, int(np_cluster[i]), hs.shape[2]) for i in range(W)], dim=1)
+    emb = torch.cat([lo, rep], dim=2)                           # [B, P, 128]
+    P = emb.shape[1]
+    h = emb.reshape(B * P, -1) @ _w2(p, "conv_2.weight").t() + p["conv_2.bias"]
+    h = torch.relu(batchnorm_rows(h, p["bn_2.weight"], p["bn_2.bias"], bufs, "bn_2.", train))
+    if drop_masks is not None:
+        h = h * drop_masks["d2"].transpose(1, 2).reshape(B * P, -1) * (1.0 / (1.0 - drop_p))
+    h = h @ _w2(p, "conv_3.weight").t() + p["conv_3.bias"]
+    h = torch.relu(batchnorm_rows(h, p["bn_3.weight"], p["bn_3.bias"], bufs, "bn_3.", train))
+    if drop_masks is not None:
+        h = h * drop_masks["d3"].transpose(1, 2).reshape(B * P, -1) * (1.0 / (1.0 - drop_p))
+    h = h @ _w2(p, "conv_4.weight").t() + p["conv_4.bias"]
+    return h.reshape(B, P, -1).transpose(1, 2)
+
+
+def forward_windows_gru(enc_p, enc_b, head_p, head_b, pc, targets, train_enc, train_head, drop_p=0.0, drop_masks=None):
+    """The model part of the GRU train_loop (pointNet/rnn/train_pointnetGRU.py:385-403): pc [B, N, 9, W], targets [B, N, W]
+    -> logits [B, C, W*N], targets_pc [B, W*N], feature_transform of the LAST window."""
+    B, N, _, W = pc.shape
+    lo, gl, tg, t_feat = [], [], [], None
+    for w in range(W):
+        l, g, t_feat = encoder(enc_p, enc_b, pc[:, :, :, w], train_enc)
+        lo.append(l)
+        gl.append(g)
+        tg.append(targets[:, :, w])
+    logits = gru_head(head_p, head_b, torch.stack(gl, dim=1), torch.cat(lo, dim=1), [N] * W, train_head, drop_p=drop_p, drop_masks=drop_masks)
+    return logits, torch.cat(tg, dim=1), t_feat
+
+
 def loss_terms(logits, targets_pc, t_feat, class_w=(1.0, 2.0, 2.0, 1.0, 1.0)):
     """(ce, reg): weighted CE with ignore_index -1, mean over non-ignored weights; Frobenius norm of
     I - F F^T over the whole [B, 64, 64] tensor (train_pointnet-attention.py:127,138,445,463-464)."""

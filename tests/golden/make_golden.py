@@ -56,6 +56,7 @@ def install_stubs():
     _stub("progressbar", progressbar=lambda x, *a, **k: x)
     _stub("laspy")
     _stub("prettytable", PrettyTable=_Dummy)
+    _stub("torchsummary", summary=lambda *a, **k: None)      # imported by pointNet/rnn/train_pointnetGRU.py:7, never called on the path
     if "torch.utils.tensorboard" not in sys.modules:
         try:
             import torch.utils.tensorboard  # noqa: F401
@@ -317,6 +318,10 @@ def sec_baseline_train():
                 if p.numel() <= 2048 and step == 1:
                     res[f"s1_grad/{k}"] = p.grad.detach().numpy()
                 res[f"s{step}_psum/{k}"] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+            if step == 1:                      # running statistics after ONE step: they depend on the step-1 forward only
+                for k, v in net.state_dict().items():
+                    if "running" in k:
+                        res[f"s1_buf/{k}"] = v.numpy().copy()
         for k, v in net.state_dict().items():
             if "running" in k:
                 res[f"final_buf/{k}"] = v.numpy()
@@ -329,7 +334,72 @@ def sec_baseline_train():
         save(tag, seed_base=np.array([base]), **res)
 
 
-SECTIONS = dict(baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
+def sec_gru():
+    """f4: SegmentationWithGRU (pointnetAtt.py:212-258) eval forwards (uniform and ragged windows) and the reference's GRU train_loop
+    (pointNet/rnn/train_pointnetGRU.py:335-441): eval, then two train steps.  The module hard-codes nn.Dropout(0.3); its p is set to 0
+    on the instance for the train steps so that they are deterministic (dropout parity is checked against the oracle with shared masks)."""
+    from pointNet.model.pointnetAtt import BasePointNet, SegmentationWithGRU
+    tr = load_script(os.path.join(REF, "pointNet/rnn/train_pointnetGRU.py"), "ref_train_gru")
+
+    def models(enc_seed, head_seed):
+        enc = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device="cpu")
+        gru = SegmentationWithGRU(num_classes=5, global_feat_size=256, hidden_size=64, device="cpu")
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_params(enc_seed, P.ENC_PARAMS).items()}
+        sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(enc_seed, P.ENC_BUFFERS).items()})
+        assert not enc.load_state_dict(sd, strict=False).unexpected_keys
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_params(head_seed, P.GRU_HEAD_PARAMS).items()}
+        sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(head_seed, P.HEAD_BUFFERS).items()})
+        missing = gru.load_state_dict(sd, strict=False)
+        assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+        assert not missing.unexpected_keys
+        return enc, gru
+
+    _, gru = models(5, 6)
+    gru.eval()
+    seq = torch.from_numpy(synth.uniform(71, (2, 3, 256), 0.0, 2.0))
+    lo = torch.from_numpy(synth.uniform(72, (2, 768, 64), -1.0, 1.0))
+    with torch.no_grad():
+        a = gru(seq, lo, [256, 256, 256])
+        b = gru(seq, lo, [100, 300, 368])
+        hs, _ = gru.gru_global(seq, gru.initHidden(seq))
+    res = dict(uniform=a.numpy(), ragged=b.numpy(), hidden=hs.numpy())
+
+    enc, gru = models(7, 8)
+    gru.dropout.p = 0.0
+    B, N, W = STEP_B, STEP_N, STEP_W
+    pc, tg, cent, w_real = synth.sample_batch(43, B, N, max_w=W, w_real=STEP_WREAL)
+    names = [f"f{i}" for i in range(B)]
+    ce = torch.nn.CrossEntropyLoss(reduction="mean", ignore_index=-1)          # train_pointnetGRU.py:148: unweighted
+    opt_p = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    opt_g = torch.optim.Adam(gru.parameters(), lr=1e-3)
+    res.update(meta=np.array([B, N, W], dtype=np.int64), w_real=w_real)
+    data = (torch.from_numpy(pc), torch.from_numpy(tg), names, torch.from_numpy(cent))
+    with torch.no_grad():
+        m, tpc, preds, _ = tr.train_loop(data, opt_p, opt_g, ce, enc, gru, None, "segmentation", False, torch.Tensor(), 0, 0)
+    res.update(eval_ce=m["ce_loss"].detach().numpy(), eval_reg=m["reg_loss"].detach().numpy(), eval_loss=m["loss"].detach().numpy(),
+               eval_targets=tpc.numpy(), eval_preds=preds.numpy())
+    for step in (1, 2):
+        data = (torch.from_numpy(pc.copy()), torch.from_numpy(tg.copy()), names, torch.from_numpy(cent))
+        m, tpc, preds, _ = tr.train_loop(data, opt_p, opt_g, ce, enc, gru, None, "segmentation", True, torch.Tensor(), 0, 0)
+        res[f"s{step}_ce"] = m["ce_loss"].detach().numpy()
+        res[f"s{step}_reg"] = m["reg_loss"].detach().numpy()
+        res[f"s{step}_loss"] = m["loss"].detach().numpy()
+        res[f"s{step}_preds"] = preds.numpy()
+        for tag, mod in (("enc", enc), ("gru", gru)):
+            for k, p in mod.named_parameters():
+                g = p.grad.detach().double()
+                res[f"s{step}_{tag}_gnorm/{k}"] = np.array([g.norm().item(), g.sum().item()])
+                if tag == "gru" and p.numel() <= 49152 and step == 1:
+                    res[f"s1_gru_grad/{k}"] = p.grad.detach().numpy()
+                res[f"s{step}_{tag}_psum/{k}"] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+        if step == 1:
+            for k, v in gru.state_dict().items():
+                if "running" in k:
+                    res[f"s1_gru_buf/{k}"] = v.numpy().copy()
+    save("gru", **res)
+
+
+SECTIONS = dict(gru=sec_gru, baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
                 collate=sec_collate, dataset=sec_dataset, baseline=sec_baseline)
 
 if __name__ == "__main__":
