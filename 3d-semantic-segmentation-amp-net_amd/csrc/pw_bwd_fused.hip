@@ -171,10 +171,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     // Gram form at 128 x 128: the matrix is symmetric, so the four W waves own the 10 tiles of its upper triangle
     // (3, 3, 2, 2) instead of all 16 and mirror them when they flush: 112 instead of 128 MFMAs per SIMD and block of rows
     constexpr bool SYM = GRAM && CX == 128 && CY == 128;
-    // wave -> (ta, tb) of its tiles, as 4-bit fields: w0 (0,0)(0,1)(1,1)  w1 (0,2)(0,3)(1,2)  w2 (1,3)(2,2)  w3 (2,3)(3,3)
-    const uint32_t sym_a = ww == 0 ? 0x100u : (ww == 1 ? 0x100u : (ww == 2 ? 0x21u : 0x32u));
-    const uint32_t sym_b = ww == 0 ? 0x110u : (ww == 1 ? 0x232u : (ww == 2 ? 0x23u : 0x33u));
-    const int sym_n = ww < 2 ? 3 : 2;
+    // waves 0, 1 own the three tiles over two column blocks {B0, B1} = {0, 1} / {2, 3}: (B0,B0) (B0,B1) (B1,B1); waves 2, 3 own
+    // (0,B2) (1,B2) with B2 = 2 / 3.  Operand A of a tile and operand B of another are the same LDS words (same lane mapping), so a
+    // wave reads each of its 2 or 3 column blocks ONCE per k step: 10 LDS reads per 10 MFMAs instead of 20 (an LDS read costs
+    // issue cycles the matrix pipe does not get back, scratch/mfma_probe2.hip)
+    const int sym_b0 = ww == 1 ? 2 : 0, sym_b1 = ww == 1 ? 3 : 1, sym_b2 = ww == 3 ? 3 : 2;
+    const bool sym3 = ww < 2;
     float wys[TYW], wyt[TYW];
 #pragma unroll
     for (int j = 0; j < TYW; ++j) {
@@ -210,30 +212,37 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         if (more && w_role) load_regs(nxt);
         const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
         if (w_role && SYM) {
-            float pa_n[3], pb_n[3];
-            auto fetch3 = [&](int s2) {
-                const int kr = 2 * s2 + h;
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    pa_n[t] = g[kr * LDG + 32 * (int)((sym_a >> (4 * t)) & 15u) + r];
-                    pb_n[t] = g[kr * LDG + 32 * (int)((sym_b >> (4 * t)) & 15u) + r];
-                }
-            };
-            fetch3(0);
+            const float *gc0 = g + 32 * sym_b0 + r, *gc1 = g + 32 * sym_b1 + r, *gc2 = g + 32 * sym_b2 + r;
+            if (sym3) {
+                float c0_n = gc0[h * LDG], c1_n = gc1[h * LDG];
 #pragma unroll 8
-            for (int s2 = 0; s2 < ROWS / 2; ++s2) {
-                float pa[3], pb[3];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    pa[t] = pa_n[t];
-                    pb[t] = pb_n[t];
+                for (int s2 = 0; s2 < ROWS / 2; ++s2) {
+                    const float c0 = c0_n, c1 = c1_n;
+                    if (s2 + 1 < ROWS / 2) {
+                        c0_n = gc0[(2 * s2 + 2 + h) * LDG];
+                        c1_n = gc1[(2 * s2 + 2 + h) * LDG];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c0, acc_w[0][0], 0, 0, 0);
+                    acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c1, acc_w[0][1], 0, 0, 0);
+                    acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c1, acc_w[1][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (s2 + 1 < ROWS / 2) fetch3(s2 + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[0], pb[0], acc_w[0][0], 0, 0, 0);
-                acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[1], pb[1], acc_w[0][1], 0, 0, 0);
-                if (sym_n == 3) acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2], pb[2], acc_w[1][0], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                float c0_n = gc0[h * LDG], c1_n = gc1[h * LDG], c2_n = gc2[h * LDG];
+#pragma unroll 8
+                for (int s2 = 0; s2 < ROWS / 2; ++s2) {
+                    const float c0 = c0_n, c1 = c1_n, c2 = c2_n;
+                    if (s2 + 1 < ROWS / 2) {
+                        c0_n = gc0[(2 * s2 + 2 + h) * LDG];
+                        c1_n = gc1[(2 * s2 + 2 + h) * LDG];
+                        c2_n = gc2[(2 * s2 + 2 + h) * LDG];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c2, acc_w[0][0], 0, 0, 0);
+                    acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c2, acc_w[0][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else if (w_role) {
             // software pipeline: the operands of step s2 + 1 are read from LDS before the MFMAs of step s2 issue, so the
@@ -353,8 +362,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            if (t >= sym_n) continue;
-            const int ta = (int)((sym_a >> (4 * t)) & 15u), tb = (int)((sym_b >> (4 * t)) & 15u);
+            if (t >= (sym3 ? 3 : 2)) continue;
+            const int ta = sym3 ? (t == 2 ? sym_b1 : sym_b0) : (t == 0 ? sym_b0 : sym_b1);
+            const int tb = sym3 ? (t == 0 ? sym_b0 : sym_b1) : sym_b2;
             const f32x16 &acc = t == 0 ? acc_w[0][0] : (t == 1 ? acc_w[0][1] : acc_w[1][0]);
             const int cy = 32 * tb + r;
 #pragma unroll

@@ -25,6 +25,7 @@ namespace ampnet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -160,18 +161,24 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     // (the T-Net FC layers normalise over only B rows of near-identical pooled features).
     // MaxPool: BatchNorm + ReLU are monotone per channel with the direction of sign(gamma) (scale = gamma * invstd), so one
     // signed extreme per channel is enough: ext = max over rows of sgn * v (the sign is folded into the staged weights).
-    float s_sum[NT], s_sq[NT], s_ext[NT], s_z0[NT], bias_v[NT];
+    // The accumulators start at bias - z0, so a finished tile holds d = z - z0 directly (no bias add, no subtraction per element:
+    // VALU instructions do not overlap with fp32 MFMAs on this part -- scratch/mfma_probe.hip -- so every epilogue instruction is
+    // time taken from the matrix pipe).  z0 is only known after the wave's first tile of the block of rows: that tile starts at
+    // bias and has z0 subtracted once it is known.
+    f32x2 s_sum2[NT], s_sq2[NT];
+    float s_ext[NT], s_z0[NT], bias_v[NT], init_v[NT];
     int s_arg[NT];
     int s_cnt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = cb0 + 32 * t + r;
         s_z0[t] = 0.f;
-        s_sum[t] = 0.f;
-        s_sq[t] = 0.f;
+        s_sum2[t] = f32x2{0.f, 0.f};
+        s_sq2[t] = f32x2{0.f, 0.f};
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
         bias_v[t] = (a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
+        init_v[t] = bias_v[t];
     }
 
     const int ntiles = (nrows + 31) / 32;
@@ -243,9 +250,13 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[t][e] = init_v[t];
 
-#pragma unroll 1
+        if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
+        // the pipelined fp32 loop is unrolled over its k blocks: the LDS offsets of the operand reads become immediates
+        // (25 integer VALU instructions per block of 64 MFMAs otherwise -- and VALU time is matrix-pipe time here)
+        constexpr int KB_UNROLL = (PIPE && !BF && CIN <= 128) ? NBLK : 1;
+#pragma unroll KB_UNROLL
         for (int kb = 0; kb < NBLK; ++kb) {
             // prefetch the next block (same tile, or block 0 of this wave's next tile)
             {
@@ -370,47 +381,75 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
         }
 
+        if (a.variant & 1) __builtin_amdgcn_s_setprio(0);
+        if (a.variant & 2) {
+            if (acc[0][0] == 123.456f) s_cnt += 1;            // keeps the MFMAs alive
+            continue;
+        }
         // ---- epilogue: lane = output channel, registers = 16 rows; predicated, no branch between elements ----
         if (do_stats) {
             if (tile == wave) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) s_z0[t] = __shfl(acc[t][0] + bias_v[t], r);   // row0 + 0 lives in lane r, register 0
+                for (int t = 0; t < NT; ++t) {
+                    const float z0 = __shfl(acc[t][0], r);            // row0 + 0 lives in lane r, register 0 (bias included)
+                    s_z0[t] = z0;
+                    init_v[t] = bias_v[t] - z0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] -= z0;
+                }
             }
             s_cnt += valid;
         }
-        // FULL: all 32 rows of the tile exist (every tile but a window's last): no row predicate at all
-        auto epilogue = [&](auto full_tag) {
+        // FULL: all 32 rows of the tile exist (every tile but a window's last): no row predicate at all.  STATS is a compile-time
+        // copy of do_stats: as a run-time flag the compiler turned every `s_sum += d` into an add AND a select
+        auto epilogue = [&](auto full_tag, auto stats_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            constexpr bool STATS = decltype(stats_tag)::value;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int col = cb0 + 32 * t + r;
                 const bool cok = col < a.cout;
+                const float z0 = STATS ? s_z0[t] : 0.f;
                 float *zp = a.Z + (size_t)row0 * a.ldz + col;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[t][e] + bias_v[t];
-                    const bool ok = FULL || rr < valid;
-                    if (do_store && ok && cok) {
-                        if (BF && ZBF) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr) * a.ldz + col] = (__bf16)v;
-                        else zp[(size_t)rr * a.ldz] = v;
+                for (int e = 0; e < 16; e += 2) {
+                    const int rr0 = (e & 3) + 8 * (e >> 2) + 4 * h;       // e even: rows rr0 and rr0 + 1
+                    const bool ok0 = FULL || rr0 < valid, ok1 = FULL || rr0 + 1 < valid;
+                    const float d0 = acc[t][e], d1 = acc[t][e + 1];
+                    if (do_store && cok) {
+                        if (BF && ZBF) {
+                            if (ok0) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0) * a.ldz + col] = (__bf16)(d0 + z0);
+                            if (ok1) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0 + 1) * a.ldz + col] = (__bf16)(d1 + z0);
+                        } else {
+                            if (ok0) zp[(size_t)rr0 * a.ldz] = d0 + z0;
+                            if (ok1) zp[(size_t)(rr0 + 1) * a.ldz] = d1 + z0;
+                        }
                     }
-                    if (do_stats) {
-                        const float d = ok ? v - s_z0[t] : 0.f;
-                        s_sum[t] += d;
-                        s_sq[t] = fmaf(d, d, s_sq[t]);
+                    if (STATS) {
+                        const f32x2 d2 = {ok0 ? d0 : 0.f, ok1 ? d1 : 0.f};
+                        s_sum2[t] += d2;
+                        s_sq2[t] = __builtin_elementwise_fma(d2, d2, s_sq2[t]);
                     }
                     if (POOL) {
-                        const float vs = ok ? v : -__builtin_inff();          // v is already sgn(gamma) * z (signed weights)
-                        const bool gt = vs > s_ext[t];               // strict: rows ascend, the first extreme wins
-                        s_ext[t] = gt ? vs : s_ext[t];
-                        s_arg[t] = gt ? row0 + rr : s_arg[t];
+                        // d is sgn(gamma) * z - z0 (signed weights): same order as z; strict compare: rows ascend, the first extreme wins
+                        const float v0 = ok0 ? d0 : -__builtin_inff(), v1 = ok1 ? d1 : -__builtin_inff();
+                        const bool g0 = v0 > s_ext[t];
+                        s_ext[t] = g0 ? v0 : s_ext[t];
+                        s_arg[t] = g0 ? row0 + rr0 : s_arg[t];
+                        const bool g1 = v1 > s_ext[t];
+                        s_ext[t] = g1 ? v1 : s_ext[t];
+                        s_arg[t] = g1 ? row0 + rr0 + 1 : s_arg[t];
                     }
                 }
             }
         };
-        if (valid == 32) epilogue(std::true_type{});
-        else epilogue(std::false_type{});
+        if (do_stats) {
+            if (valid == 32) epilogue(std::true_type{}, std::true_type{});
+            else epilogue(std::false_type{}, std::true_type{});
+        } else {
+            if (valid == 32) epilogue(std::true_type{}, std::false_type{});
+            else epilogue(std::false_type{}, std::false_type{});
+        }
     }
 
     if (!do_stats && !POOL) continue;
@@ -421,7 +460,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     int *red_n = red_i + PW_NW * CB;                               // [PW_NW] rows seen by the wave
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float o_sum = __shfl_xor(s_sum[t], 32), o_sq = __shfl_xor(s_sq[t], 32);
+        const float m_sum = s_sum2[t][0] + s_sum2[t][1], m_sq = s_sq2[t][0] + s_sq2[t][1];
+        const float o_sum = __shfl_xor(m_sum, 32), o_sq = __shfl_xor(m_sq, 32);
         const float o_ext = __shfl_xor(s_ext[t], 32);
         const int o_arg = __shfl_xor(s_arg[t], 32);
         float f_ext = s_ext[t];
@@ -432,9 +472,9 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
         if (h == 0) {
             const int c = 32 * t + r;
-            red_f[(wave * CB + c) * 4 + 0] = s_sum[t] + o_sum;
-            red_f[(wave * CB + c) * 4 + 1] = s_sq[t] + o_sq;
-            red_f[(wave * CB + c) * 4 + 2] = f_ext;
+            red_f[(wave * CB + c) * 4 + 0] = m_sum + o_sum;
+            red_f[(wave * CB + c) * 4 + 1] = m_sq + o_sq;
+            red_f[(wave * CB + c) * 4 + 2] = f_ext + s_z0[t];     // back from d = z - z0 (the waves have different z0)
             red_f[(wave * CB + c) * 4 + 3] = s_z0[t];
             red_i[wave * CB + c] = f_arg;
         }
@@ -549,8 +589,10 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
     return pro ? launch_pw_x<CIN, NT, 1, false>(a, st) : launch_pw_x<CIN, NT, 0, false>(a, st);
 }
 
-int pw_gemm(const PwGemm &a, hipStream_t st)
+int pw_gemm(const PwGemm &a_in, hipStream_t st)
 {
+    PwGemm a = a_in;
+    if (const char *ve = getenv("AMPNET_PW_VARIANT")) a.variant = atoi(ve);
     AMPNET_REQUIRE(a.A && a.W && a.win_off, "pw_gemm: null pointer");
     AMPNET_REQUIRE(a.Q >= 1 && a.chunks >= 1 && a.cout >= 1, "pw_gemm: bad sizes Q=%d chunks=%d cout=%d", a.Q, a.chunks, a.cout);
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
