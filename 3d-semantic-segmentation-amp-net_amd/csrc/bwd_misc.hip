@@ -78,7 +78,10 @@ int bn_bwd_finalize(const BnBwdFinalize &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.part_a && a.part_b && a.win_off && a.gamma && a.mean && a.invstd && a.P1 && a.P2 && a.P3 && a.slot_ab, "bn_bwd_finalize: null pointer");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * BFIN_G), 0, st, a);
-    return check_launch("bn_bwd_finalize_kernel");
+    int rc = check_launch("bn_bwd_finalize_kernel");
+    if (rc == AMPNET_OK && sync_bn_on())       // global batch: the constants again, from the all-reduced sums (slot_ab stays the rank's own)
+        rc = sync_bn_bwd_constants(a.slot_ab, a.win_off, a.Q, a.n_slots, a.uniform_rows, a.C, a.gamma, nullptr, a.mean, a.invstd, a.P1, a.P2, a.P3, st);
+    return rc;
 }
 
 constexpr int MAX_BN_ITEMS = 24;
@@ -184,7 +187,10 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.d_pooled && a.arg && a.zext && a.scale && a.shift && a.mean && a.invstd && a.win_off && a.dpm && a.P1 && a.P2 && a.P3 && a.slot_ab, "pool_bwd: null pointer");
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * PB_G), 0, st, a);
-    return check_launch("pool_bwd_kernel");
+    int rc = check_launch("pool_bwd_kernel");
+    if (rc == AMPNET_OK && sync_bn_on())
+        rc = sync_bn_bwd_constants(a.slot_ab, a.win_off, a.Q, a.n_slots, 0, a.C, nullptr, a.scale, a.mean, a.invstd, a.P1, a.P2, a.P3, st);
+    return rc;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -412,7 +418,9 @@ int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *
               int n_slots, int per, int C, float *g, float *slot_ab, hipStream_t st)
 {
     hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3(n_slots, cdiv(C, 64)), dim3(64 * FCB_G), 0, st, da, z, scale, shift, mean, invstd, per, C, g, slot_ab);
-    return check_launch("fc_bn_bwd_kernel");
+    int rc = check_launch("fc_bn_bwd_kernel");
+    if (rc == AMPNET_OK && sync_bn_on()) rc = sync_bn_fc_apply(da, z, scale, shift, mean, invstd, slot_ab, n_slots, per, C, g, st);
+    return rc;
 }
 
 // block = 32 columns x 8 row groups, fixed summation order

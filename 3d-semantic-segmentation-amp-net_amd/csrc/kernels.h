@@ -89,7 +89,20 @@ struct BnFinalize {
     float *stat_mean = nullptr, *stat_uvar = nullptr;   // [n_slots, C] batch mean / unbiased var for the running update
     const int *part_rows = nullptr; // explicit rows per partial [Q * chunks] (instead of win_off / chunk_rows)
     float *merge_ws = nullptr;     // optional scratch, bn_finalize_merge_floats(n_slots, C) floats: enables the two-stage form
+    // global-batch form (sync_bn.hip): the partial arrays are `gather_ranks` segments of `gather_seg` floats, one per rank, each
+    // {mean [n_slots, C], M2 [n_slots, C], rows [n_slots] as int}; partial (rank, slot) belongs to slot `slot`
+    int gather_ranks = 0;
+    long gather_seg = 0;
 };
+// ---- global-batch BatchNorm across data-parallel ranks (sync_bn.hip; ampnet_set_collective) ----
+bool sync_bn_on();
+int sync_bn_world();
+int sync_bn_gather(size_t seg_floats, float **local_seg, float **gathered);
+int sync_bn_exchange(int op, float *send, float *recv, size_t n_floats, hipStream_t st);
+int sync_bn_bwd_constants(const float *slot_ab, const int *win_off, int Q, int n_slots, int uniform_rows, int C, const float *gamma,
+                          const float *scale, const float *mean, const float *invstd, float *P1, float *P2, float *P3, hipStream_t st);
+int sync_bn_fc_apply(const float *da, const float *z, const float *scale, const float *shift, const float *mean, const float *invstd,
+                     const float *slot_ab, int n_slots, int per, int C, float *g, hipStream_t st);
 inline size_t bn_finalize_merge_floats(int n_slots, int C) { return (size_t)n_slots * 16 * (2 * (size_t)C + 1); }
 int bn_finalize(const BnFinalize &a, hipStream_t st);
 

@@ -132,6 +132,12 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a, f
         const int ch = e - qi * a.chunks;
         const int q = slot + qi * a.n_slots;
         const int p = q * a.chunks + ch;
+        if (a.gather_ranks > 0) {        // partial qi = rank qi's merged slot: segment {mean, M2, rows}
+            const float *seg = a.part_sum + (size_t)qi * a.gather_seg;
+            rows = reinterpret_cast<const int *>(seg + (size_t)2 * a.n_slots * a.C)[slot];
+            off = (size_t)qi * a.gather_seg + (size_t)slot * a.C + c;
+            return;
+        }
         if (a.part_rows) {
             rows = a.part_rows[p];
         } else {
@@ -220,6 +226,26 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a, f
 int bn_finalize(const BnFinalize &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.part_sum && a.part_sq && (a.win_off || a.part_rows) && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
+    if (sync_bn_on()) {
+        // global batch: merge the rank's partials per slot, all-gather the (rows, mean, M2) of every rank, finalize from those
+        const size_t seg = (size_t)a.n_slots * (2 * (size_t)a.C + 1);
+        float *loc = nullptr, *all = nullptr;
+        int rc = sync_bn_gather(seg, &loc, &all);
+        if (rc != AMPNET_OK) return rc;
+        float *m_sum = loc, *m_sq = loc + (size_t)a.n_slots * a.C;
+        int *m_rows = reinterpret_cast<int *>(m_sq + (size_t)a.n_slots * a.C);
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, a, m_sum, m_sq, m_rows);
+        rc = check_launch("bn_finalize_kernel (rank merge)");
+        if (rc != AMPNET_OK) return rc;
+        rc = sync_bn_exchange(AMPNET_COLLECTIVE_ALLGATHER, loc, all, seg, st);
+        if (rc != AMPNET_OK) return rc;
+        BnFinalize s2 = a;
+        s2.part_sum = all; s2.part_sq = all + (size_t)a.n_slots * a.C;
+        s2.gather_ranks = sync_bn_world(); s2.gather_seg = (long)seg;
+        s2.Q = sync_bn_world() * a.n_slots; s2.chunks = 1; s2.uniform_rows = 0; s2.part_rows = nullptr;
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * FIN_G), 0, st, s2, nullptr, nullptr, nullptr);
+        return check_launch("bn_finalize_kernel (global batch)");
+    }
     const long per_slot_parts = (long)((a.Q + a.n_slots - 1) / a.n_slots) * a.chunks;
     if (a.merge_ws && per_slot_parts >= 128 && a.n_slots * FIN_V <= a.Q) {
         // few slots, thousands of partials each (the head: one slot): merge FIN_V sub-slots per slot on FIN_V x more

@@ -77,11 +77,17 @@ def reduce_epoch_metrics(sums, ious, device=None):
 
 
 def train_att(task, dataset_folder, path_list_files, output_folder, n_points, batch_size, epochs, learning_rate,
-              weighing_method='EFS', beta=0.999, number_of_workers=4, model_checkpoint=None, device='cuda'):
+              weighing_method='EFS', beta=0.999, number_of_workers=4, model_checkpoint=None, device='cuda', sync_bn=None):
+    """sync_bn (default: AMPNET_SYNC_BN=1 in the environment): under data parallelism, BatchNorm statistics and the loss normalisation
+    over the GLOBAL batch, i.e. the single-device semantics of the reference at batch_size x world (trainer.enable_sync_batchnorm);
+    off, every rank normalises over its own batch_size samples."""
     if task != 'segmentation':
         raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
     start = time.time()
     rank, world, local = _dist_setup()
+    if world > 1 and (sync_bn if sync_bn is not None else os.environ.get("AMPNET_SYNC_BN") == "1"):
+        from ..trainer import enable_sync_batchnorm
+        enable_sync_batchnorm()
     device = torch.device('cuda', local)
     with open(os.path.join(path_list_files, 'train_seg_files.txt')) as f:
         train_files = f.read().splitlines()

@@ -105,6 +105,70 @@ def _dist_world():
     return None, 1
 
 
+_SYNC = {"on": False}
+
+
+def enable_sync_batchnorm():
+    """Global-batch BatchNorm under data parallelism (include/ampnet_hip.h: ampnet_set_collective; SURVEY section 8(e) option A): every
+    train-mode BatchNorm of the HIP launch sequences merges its statistics over all ranks, and forward_backward normalises the loss
+    over the global batch, so that a step of N ranks equals the single-process step on the concatenated batch.  The exchanges are
+    torch.distributed collectives (RCCL under the nccl backend) on views of a scratch tensor this function keeps alive.
+    Call after init_process_group, with the rank's device current.  Returns True when it took effect (world size > 1)."""
+    dist, world = _dist_world()
+    if world <= 1:
+        return False
+    L = _lib.lib()
+    L.ampnet_collective_scratch_bytes.restype = ctypes.c_size_t
+    nbytes = L.ampnet_collective_scratch_bytes(world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    scratch = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+    base = scratch.data_ptr()
+    proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    state = {"error": None}
+
+    def collective(ctx, op, send, recv, n, stream):
+        try:
+            if (stream or 0) != torch.cuda.current_stream(dev).cuda_stream:
+                raise _lib.AmpnetError("sync BatchNorm: the launch stream is not torch's current stream")
+            s0, r0 = (send - base) // 4, (recv - base) // 4
+            if op == 1:
+                dist.all_reduce(scratch[s0:s0 + n], op=dist.ReduceOp.SUM)
+            else:
+                out, inp = scratch[r0:r0 + world * n], scratch[s0:s0 + n]
+                try:
+                    dist.all_gather_into_tensor(out, inp)
+                except (RuntimeError, NotImplementedError):
+                    dist.all_gather(list(out.chunk(world)), inp)
+            return 0
+        except Exception as e:                       # an exception must not unwind through the C frames
+            state["error"] = e
+            return 1
+
+    cb = proto(collective)
+    with torch.cuda.device(dev):
+        rc = L.ampnet_set_collective(cb, None, dist.get_rank(), world, ctypes.c_void_p(base), ctypes.c_size_t(nbytes))
+    _lib.check(rc, "ampnet_set_collective")
+    _SYNC.update(on=True, cb=cb, scratch=scratch, state=state, world=world)
+    return True
+
+
+def disable_sync_batchnorm():
+    if _SYNC.get("on"):
+        _lib.check(_lib.lib().ampnet_set_collective(None, None, 0, 1, None, ctypes.c_size_t(0)), "ampnet_set_collective")
+    _SYNC.clear()
+    _SYNC["on"] = False
+
+
+def _global_loss(loss2, reg):
+    """Loss terms of the GLOBAL batch from the rank's (weighted-mean CE, sum of weights) and reg = || I - F F^T || over its own samples:
+    ce_g = sum_r ce_r sw_r / sum_r sw_r, reg_g = sqrt(sum_r reg_r^2).  Returns (loss2 for ampnet_ce_bwd_f32, reg for ampnet_reg_loss_bwd_f32,
+    world): the backward seeds are world x d(global loss)/d(local tensors), because the gradient all-reduce is followed by 1 / world."""
+    dist, world = _dist_world()
+    pack = torch.stack([loss2[0] * loss2[1], loss2[1], reg.reshape(-1)[0] ** 2])
+    dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    return torch.stack([pack[0] / pack[1], pack[1] / world]), pack[2].sqrt().reshape(1), world
+
+
 def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.001):
     """Forward + loss + backward of one batch; gradients land in p.grad (views of the modules' flat buffers).
     x [B, W, N, 9] f32, t [B, W, N] i64 (host or device), centroids [B, W, 2]."""
@@ -146,6 +210,11 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     # ---- backward ----
     if not hasattr(att_net, "_bws"):
         att_net._bws, pointnet._bws = ops.Workspace(), ops.Workspace()
+    if _SYNC["on"]:
+        if _SYNC["state"]["error"] is not None:
+            raise _SYNC["state"]["error"]
+        loss2, reg_b, world = _global_loss(loss2, reg)      # reported ce / reg are the global batch's; seeds scaled by world (see there)
+        reg, reg_weight = reg_b, reg_weight * world
     dlog = ops.ce_backward(logits, tgd, class_w, loss2)
     if gru:
         d_lo, d_gl = ops.gru_head_backward(hpt, hg.table, glob, local, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,

@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational legs (train_loop_inclusive, fps)")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: BatchNorm statistics and loss normalisation over the global batch "
+                                                           "(36 more latency-bound collectives per step; default: per-rank statistics)")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train", "bf16_store"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
@@ -372,6 +374,8 @@ def main():
 
     if args.mode == "fps":
         return bench_fps(args, dev, rank, world, dist)
+    if world > 1 and args.sync_bn:
+        sub("trainer").enable_sync_batchnorm()
 
     trainer_mod = None
     try:
@@ -507,7 +511,8 @@ def main():
                                           "bf16_store": "bf16 MFMA operands + bf16 stored activations, f32 accumulate / statistics / gradients"}[args.precision], "data": "synthetic",
             "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
-                       "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "batchnorm": ("global batch" if (world > 1 and args.sync_bn) else ("per rank" if world > 1 else "single device"))},
             "ms_per_window": round(dt / args.steps * 1e3 / (B * N_WIN), 5),
             "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),

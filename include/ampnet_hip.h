@@ -226,6 +226,26 @@ int ampnet_kmeans_balanced_f32(const float *feat, int n, int k, int size_min, in
                                uint32_t seed, int32_t *labels, float *centres, double *inertia, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* ---- global-batch BatchNorm under data parallelism (process-wide; SURVEY section 8(e) option A) ---------------------------------
+ * The reference is single-device: its BatchNorm layers see the whole batch.  With a collective registered and world_size > 1,
+ * every TRAIN-mode BatchNorm inside ampnet_encoder_fwd_f32 / _bwd_f32, ampnet_head_* and ampnet_gru_head_* uses the statistics of the
+ * global batch: the forward all-gathers the per-slot (rows, mean, M2) of every rank and merges them (Chan), the backward all-reduces
+ * the per-slot (sum dy, sum dy zhat, rows).  Running statistics are then identical on every rank.  The library calls `fn` on the host,
+ * between two launches:
+ *   op AMPNET_COLLECTIVE_ALLGATHER      recv[k * n_floats .. ] = rank k's send[0 .. n_floats)      (recv holds world_size * n_floats)
+ *   op AMPNET_COLLECTIVE_ALLREDUCE_SUM  send == recv: element-wise float32 sum over the ranks, in place
+ * send / recv point into `scratch` (device memory of ampnet_collective_scratch_bytes(world_size) bytes the caller owns and keeps
+ * alive); the exchange must be ordered after the work already enqueued on `stream` and before what is enqueued after fn returns
+ * (torch.distributed on the current stream does that).  fn returns 0 on success.  fn = NULL switches back to per-rank statistics.
+ * 18 + 18 latency-bound collectives per AMP-Net step: off by default (per-rank BatchNorm is the documented deviation). */
+#define AMPNET_COLLECTIVE_ALLGATHER 0
+#define AMPNET_COLLECTIVE_ALLREDUCE_SUM 1
+#define AMPNET_SYNC_MAX_SLOTS 32
+#define AMPNET_SYNC_MAX_CHANNELS 256
+typedef int (*ampnet_collective_fn)(void *ctx, int op, void *send, void *recv, size_t n_floats, void *stream);
+size_t ampnet_collective_scratch_bytes(int world_size);
+int ampnet_set_collective(ampnet_collective_fn fn, void *ctx, int rank, int world_size, void *scratch, size_t scratch_bytes);
+
 /* ---- matrix-core operand precision (process-wide) -----------------------------------------------------------
  * AMPNET_PRECISION_F32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products -- the mode every parity figure is quoted in.
  * AMPNET_PRECISION_BF16: the per-point layers of ampnet_encoder_fwd_f32 / ampnet_head_fwd_f32 round their MFMA operands

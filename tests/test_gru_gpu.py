@@ -161,7 +161,10 @@ def test_gru_train_loop_first_step_matches_reference(golden, synth, params):
             worst = max(worst, err / (nrm + 1e-5 * gtot))
             ps = g[f"s1_{tag}_psum/{k}"]
             have = p.detach().double().abs().sum().item()
-            if abs(have - ps[1]) > 2e-4 * abs(ps[1]) + 2.1e-3 * max(1.0, 0.02 * p.numel()):
+            # a bias in front of a BatchNorm (conv_2.bias, conv_3.bias) has an analytically zero gradient: Adam divides rounding noise by
+            # its own magnitude and moves every element by +-lr in a direction that is noise, in the reference as well
+            atol = 1.1e-3 * p.numel() if gn[0] < 1e-6 * gtot else 2.1e-3 * max(1.0, 0.02 * p.numel())
+            if abs(have - ps[1]) > 2e-4 * abs(ps[1]) + atol:
                 bad.append(("psum", tag, k, have, float(ps[1])))
     print(f"GRU train step: worst relative gradient error vs float64 {worst:.2e}")
     assert not bad, bad
