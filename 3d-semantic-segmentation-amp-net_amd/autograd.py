@@ -120,3 +120,34 @@ def gru_head_apply(module, pt, bt, gl_rows, lo_rows, off, B, W, total, mx, n_cla
     torch._foreach_add_([module.bn_2.num_batches_tracked, module.bn_3.num_batches_tracked], 1)
     preds = logits.detach().argmax(dim=1) if want_preds else None
     return logits, preds, None
+
+
+class _ClsHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, gl, *params):
+        module, pt, bt, mask, B, W, n_classes, p_drop, seed = meta
+        ws = ops.Workspace()
+        out, aw = ops.cls_head_forward(pt, bt, gl, mask, B, W, n_classes, True, p_drop, seed, ws)
+        ctx.save_for_backward(gl)
+        ctx.meta = (module, pt, B, W, n_classes, p_drop, seed, ws)
+        ctx.mark_non_differentiable(aw)
+        return out, aw
+
+    @staticmethod
+    def backward(ctx, d_out, _d_aw):
+        module, pt, B, W, n_classes, p_drop, seed, ws = ctx.meta
+        gl, = ctx.saved_tensors
+        table = module._param_table()
+        named = dict(module.named_parameters())
+        grads = {n: torch.empty_like(named[n]) for n in table}
+        gt = ops.PointerTable(table, grads, "classification head gradients")
+        d_gl = ops.cls_head_backward(pt, gt, gl, B, W, n_classes, p_drop, seed, d_out.contiguous().float(), ws, ops.Workspace())
+        ctx.meta = None
+        return (None, d_gl) + tuple(grads[n] for n in table)
+
+
+def cls_head_apply(module, pt, bt, gl_rows, mask, B, W, n_classes, p_drop, seed):
+    params = _ordered_params(module, module._param_table())
+    out, aw = _ClsHeadFn.apply((module, pt, bt, mask, B, W, n_classes, p_drop, seed), gl_rows.contiguous().float(), *params)
+    module.bn_2.num_batches_tracked += 1
+    return out, aw

@@ -93,6 +93,9 @@ int posenc_tokens(const float *gl, const float *cent, const float *w1, const flo
 // softmax(q k^T / sqrt(d) + mask) [dropout] v per (sample, head)      (nn.MultiheadAttention core)
 int attention_core(const float *qkv, const uint8_t *key_pad_mask, float *probs, float *ctx, int B, int W, float drop_p,
                    uint32_t drop_base, hipStream_t st);
+// gradients of the above wrt q, k, v given d(ctx): dqkv [Q, 768]
+int attention_core_bwd(const float *qkv, const float *probs, const float *dctx, float *dqkv, int B, int W, float drop_p, uint32_t drop_base,
+                       hipStream_t st);
 // logits[b, c, p] = conv_4(dropout(relu(bn_3(z3))))[row = b * P + p]; optional weighted CE partials + argmax
 struct HeadOut {
     const float *z3 = nullptr;             // [R, 64]

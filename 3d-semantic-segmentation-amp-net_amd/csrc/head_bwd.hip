@@ -268,6 +268,13 @@ void head_bwd_carve(const HeadShape &s, void *base, HeadBwdWs &w)
 }
 
 
+int attention_core_bwd(const float *qkv, const float *probs, const float *dctx, float *dqkv, int B, int W, float drop_p, uint32_t drop_base_,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(attention_core_bwd_kernel, dim3(B, HEAD_HEADS), dim3(64), 0, st, qkv, probs, dctx, dqkv, W, drop_p, drop_base_);
+    return check_launch("attention_core_bwd_kernel");
+}
+
 int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPointParams &p_, const HeadPointGrads &g, const float *lo,
                     const int32_t *win_off, float drop_p, uint32_t seed, const float *dlogits, float *d_lo, hipStream_t st)
 {
@@ -429,9 +436,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     TRY(sgemm_linear_bwd(Q, 128, 256, d_gbias, 128, f.g2, 256, P[HP_CONV2_W] + 64, 320, G[HP_CONV2_W] + 64, 320, b.d_g2, 256, st));
     TRY(sgemm_linear_bwd(Q, 256, 256, b.d_g2, 256, f.ctx, 256, P[HP_OUTPROJ_W], 256, G[HP_OUTPROJ_W], 256, b.d_ctx, 256, st));
     TRY(colsum(b.d_g2, Q, 256, G[HP_OUTPROJ_B], st));
-    hipLaunchKernelGGL(attention_core_bwd_kernel, dim3(B, HEAD_HEADS), dim3(64), 0, st, f.qkv, f.probs, b.d_ctx, b.d_qkv, W, drop_p,
-                       drop_base(seed, 0));
-    TRY(check_launch("attention_core_bwd_kernel"));
+    TRY(attention_core_bwd(f.qkv, f.probs, b.d_ctx, b.d_qkv, B, W, drop_p, drop_base(seed, 0), st));
     TRY(sgemm_linear_bwd(Q, 768, 256, b.d_qkv, 768, f.tok, 256, P[HP_INPROJ_W], 256, G[HP_INPROJ_W], 256, d_gl, 256, st));   // d_tok = d_gl = d_pos
     TRY(colsum(b.d_qkv, Q, 768, G[HP_INPROJ_B], st));
     // ---- positional encoding: pos = leaky(cent W1^T + b1) W2^T + b2 --------------------------------------------

@@ -192,6 +192,50 @@ def gru_head_backward(head_params, grad_table, gl, lo, win_off, B, W, total_rows
     return d_lo, d_gl
 
 
+def cls_head_forward(head_params, head_buffers, gl, mask, B, W, n_classes, train, drop_p, seed, ws, want_weights=True):
+    """ClassificationWithAttention on the HIP path: gl [B*W, 256] (row b*W+w), mask [B, W] or None -> (out [B, C], attention weights
+    [B, W, W] or None).  See include/ampnet_hip.h: ampnet_cls_head_fwd_f32."""
+    _lib.require_gpu(gl, "gl")
+    if gl.dtype != torch.float32 or tuple(gl.shape) != (B * W, P.GLOBAL_DIM):
+        raise _lib.AmpnetError(f"cls_head_forward: gl must be float32 [B*W={B * W}, 256], got {tuple(gl.shape)} {gl.dtype}")
+    dev = gl.device
+    gl = gl.contiguous()
+    m8 = None
+    if mask is not None:
+        m8 = mask.to(device=dev, dtype=torch.uint8).contiguous()
+        if tuple(m8.shape) != (B, W):
+            raise _lib.AmpnetError(f"cls_head_forward: mask {tuple(m8.shape)} != [B={B}, W={W}]")
+    L = _lib.lib()
+    L.ampnet_cls_head_workspace_bytes.restype = ctypes.c_size_t
+    buf = ws.get(L.ampnet_cls_head_workspace_bytes(B, W), dev)
+    out = torch.empty((B, n_classes), dtype=torch.float32, device=dev)
+    aw = torch.empty((B, W, W), dtype=torch.float32, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        rc = L.ampnet_cls_head_fwd_f32(head_params.arr, head_buffers.arr, _lib.ptr(gl), _lib.ptr(m8), B, W, n_classes, int(train),
+                                       ctypes.c_float(drop_p), ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(out), _lib.ptr(aw), _lib.ptr(buf),
+                                       ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_cls_head_fwd_f32")
+    return out, aw
+
+
+def cls_head_backward(head_params, grad_table, gl, B, W, n_classes, drop_p, seed, d_out, fwd_ws, bwd_ws):
+    """Backward of a train-mode cls_head_forward (same arguments, fwd_ws untouched since) -> d_gl [B*W, 256]."""
+    dev = gl.device
+    L = _lib.lib()
+    L.ampnet_cls_head_bwd_workspace_bytes.restype = ctypes.c_size_t
+    buf = bwd_ws.get(L.ampnet_cls_head_bwd_workspace_bytes(B, W), dev)
+    fbuf = fwd_ws.buf
+    if tuple(d_out.shape) != (B, n_classes) or d_out.dtype != torch.float32 or not d_out.is_contiguous():
+        raise _lib.AmpnetError(f"cls_head_backward: d_out must be contiguous float32 [B, C], got {tuple(d_out.shape)}")
+    d_gl = torch.empty((B * W, P.GLOBAL_DIM), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.ampnet_cls_head_bwd_f32(head_params.arr, grad_table.arr, _lib.ptr(gl.contiguous()), B, W, n_classes, ctypes.c_float(drop_p),
+                                       ctypes.c_uint32(seed & 0xFFFFFFFF), _lib.ptr(d_out), _lib.ptr(d_gl), _lib.ptr(fbuf),
+                                       ctypes.c_size_t(fbuf.numel()), _lib.ptr(buf), ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_cls_head_bwd_f32")
+    return d_gl
+
+
 def reg_loss(feat_T, keep_G=False):
     """|| I - F F^T ||_F over the stack feat_T [n, 64, 64] -> device scalar tensor [1] (and G when keep_G)."""
     _lib.require_gpu(feat_T, "feat_T")

@@ -100,6 +100,21 @@ GRU_HEAD_PARAMS = OrderedDict([
 ])
 
 
+def cls_head_params(num_classes=2, num_w=9):
+    """ClassificationWithAttention (pointnetAtt.py:115-133), state_dict order."""
+    return OrderedDict([
+        ("attention.in_proj_weight", (3 * GLOBAL_DIM, GLOBAL_DIM)), ("attention.in_proj_bias", (3 * GLOBAL_DIM,)),
+        ("attention.out_proj.weight", (GLOBAL_DIM, GLOBAL_DIM)), ("attention.out_proj.bias", (GLOBAL_DIM,)),
+        ("conv_1.weight", (1, num_w, 1)), ("conv_1.bias", (1,)),
+        ("fc_2.weight", (128, GLOBAL_DIM)), ("fc_2.bias", (128,)),
+        ("fc_3.weight", (num_classes, 128)), ("fc_3.bias", (num_classes,)),
+        ("bn_2.weight", (128,)), ("bn_2.bias", (128,)),
+    ])
+
+
+CLS_HEAD_BUFFERS = OrderedDict(_bn_bufs("bn_2.", 128))
+
+
 def numel(shape):
     n = 1
     for s in shape:

@@ -340,3 +340,51 @@ class ClassificationFromGRU(nn.Module):
     def forward(self, x):
         raise AttributeError("'ClassificationFromGRU' object has no attribute 'embed_dim' (the reference's forward fails the same way, "
                              "pointnetAtt.py:274; the classification task is not runnable in the reference)")
+
+
+class ClassificationWithAttention(nn.Module):
+    """pointnetAtt.py:115-151 on the HIP path (ampnet_cls_head_fwd_f32 / _bwd_f32, csrc/cls_head.hip): MultiheadAttention over the window
+    tokens, conv_1 = Conv1d(num_w -> 1, 1) over the attention output re-viewed as [B, W, E] (a view of the sequence-first tensor, as the
+    reference writes it), fc_2 -> bn_2 -> ReLU -> fc_3.  forward(gl_feats [W, B, E], centroids, attn_mask) -> (out [B, C], weights
+    [B, W, W]); centroids are unused by the reference (the positional encoding is commented out there)."""
+
+    def __init__(self, embed_dim, num_heads, num_classes=2, dropout=0.3, num_w=9, device='cuda'):
+        super().__init__()
+        if embed_dim != P.GLOBAL_DIM or num_heads != P.HEADS or not (1 <= num_classes <= 16) or not (1 <= num_w <= 32):
+            raise NotImplementedError("the HIP classification head is built for embed_dim=256, num_heads=8, num_classes<=16, num_w<=32")
+        self.embed_dim = embed_dim
+        self.num_classes, self.num_w = num_classes, num_w
+        self.p_drop = float(dropout)
+        self.attention = _MHA(embed_dim, device)
+        self.conv_1 = _Conv(num_w, 1, True, device)
+        self.fc_2 = _Linear(embed_dim, 128, True, device)
+        self.fc_3 = _Linear(128, num_classes, True, device)
+        self.bn_2 = _BN(128, device)
+        self._cache = _TableCache()
+        self._ws = ops.Workspace()
+        self._step = 0
+        self.seed = 0x3C6EF372
+
+    def _param_table(self):
+        return P.cls_head_params(self.num_classes, self.num_w)
+
+    def _tables(self):
+        return self._cache.get(self, self._param_table(), P.CLS_HEAD_BUFFERS, "ClassificationWithAttention")
+
+    def forward(self, gl_feats, centroids=None, attn_mask=None):
+        W, B = gl_feats.shape[0], gl_feats.shape[1]
+        if W != self.num_w:
+            raise _lib.AmpnetError(f"ClassificationWithAttention: {W} tokens per sample, conv_1 was built for num_w={self.num_w}")
+        gl_rows = gl_feats.transpose(0, 1).reshape(B * W, self.embed_dim)
+        pt, bt = self._tables()
+        train = self.training
+        seed = (self.seed + 0x632BE5AB * self._step) & 0xFFFFFFFF
+        if train:
+            self._step += 1
+        if train and torch.is_grad_enabled() and (gl_feats.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ...autograd import cls_head_apply
+            return cls_head_apply(self, pt, bt, gl_rows, attn_mask, B, W, self.num_classes, self.p_drop, seed)
+        out = ops.cls_head_forward(pt, bt, gl_rows.contiguous().float(), attn_mask, B, W, self.num_classes, train, self.p_drop, seed, self._ws)
+        if train:
+            self.bn_2.num_batches_tracked += 1
+        return out

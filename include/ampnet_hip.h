@@ -181,6 +181,26 @@ int ampnet_gru_head_bwd_f32(const float *const *params_host, float *const *grads
                             const float *dlogits, float *d_lo, float *d_gl, void *fwd_workspace, size_t fwd_workspace_bytes,
                             void *bwd_workspace, size_t bwd_workspace_bytes, void *stream);
 
+/* ---- f4: classification head on the window tokens ------------------------------------------------------------------------
+ * replaces ClassificationWithAttention.forward (pointNet/model/pointnetAtt.py:115-151): MultiheadAttention over the W tokens of a sample,
+ * conv_1 (Conv1d(num_w -> 1, 1)) over the attention output RE-VIEWED as [B, W, 256] (the reference views the sequence-first tensor, it
+ * does not transpose it; restated literally), fc_2 -> bn_2 (over the B rows) -> ReLU -> fc_3.  No reference script reaches this module
+ * (train_pointnet-attention.py:440-442 leaves the classification branch without a model call); built for the module's own contract.
+ *   params_host  [12] attention.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, conv_1.weight [1, W, 1], conv_1.bias [1],
+ *                fc_2.weight [128, 256], fc_2.bias, fc_3.weight [C, 128], fc_3.bias, bn_2.weight, bn_2.bias
+ *   buffers_host [2]  bn_2.running_mean, bn_2.running_var
+ *   gl [B * W, 256] (row b * W + w = gl_feats[w, b, :]); key_pad_mask [B, W] or NULL; out [B, n_classes];
+ *   attn_weights [B, W, W] or NULL: the attention probabilities averaged over the heads (after dropout in train mode), need_weights=True */
+size_t ampnet_cls_head_workspace_bytes(int B, int W);
+int ampnet_cls_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl, const uint8_t *key_pad_mask, int B,
+                            int W, int n_classes, int train, float drop_p, uint32_t seed, float *out, float *attn_weights, void *workspace,
+                            size_t workspace_bytes, void *stream);
+/* autograd backward given d_out [B, n_classes] (after a train-mode forward with the same arguments): grads_host [12] WRITTEN, d_gl [B * W, 256] */
+size_t ampnet_cls_head_bwd_workspace_bytes(int B, int W);
+int ampnet_cls_head_bwd_f32(const float *const *params_host, float *const *grads_host, const float *gl, int B, int W, int n_classes, float drop_p,
+                            uint32_t seed, const float *d_out, float *d_gl, void *fwd_workspace, size_t fwd_workspace_bytes,
+                            void *bwd_workspace, size_t bwd_workspace_bytes, void *stream);
+
 /* ---- a6: loss recipe (train_pointnet-attention.py:138,445,463-467) ------------------------------------
  * reg = || I - F F^T ||_F over the whole stack feat_T [n, 64, 64] (torch.norm of a 3-D tensor = Frobenius over
  * all elements).  G [n, 64, 64] (optional) receives I - F F^T for the backward; part [n] is scratch.

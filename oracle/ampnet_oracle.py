@@ -219,6 +219,30 @@ def forward_windows_gru(enc_p, enc_b, head_p, head_b, pc, targets, train_enc, tr
     return logits, torch.cat(tg, dim=1), t_feat
 
 
+def cls_head(p, bufs, gl, mask, train, heads=8, drop_p=0.0, drop_mask=None):
+    """ClassificationWithAttention.forward (pointnetAtt.py:134-151): gl [W, B, 256], mask [B, W] bool or None
+    -> (out [B, C], attention weights [B, W, W] = mean over the heads of the (dropped) probabilities)."""
+    W, B, E = gl.shape
+    d = E // heads
+    qkv = gl.reshape(W * B, E) @ p["attention.in_proj_weight"].t() + p["attention.in_proj_bias"]
+    q, k, v = qkv.split(E, dim=1)
+    hf = lambda t: t.reshape(W, B * heads, d).transpose(0, 1)            # noqa: E731
+    q, k, v = hf(q) * (1.0 / math.sqrt(d)), hf(k), hf(v)
+    s = torch.bmm(q, k.transpose(1, 2))
+    if mask is not None:
+        s = s.masked_fill(mask.reshape(B, 1, 1, W).expand(B, heads, W, W).reshape(B * heads, W, W), float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    if drop_mask is not None:
+        a = a * drop_mask * (1.0 / (1.0 - drop_p))
+    o = torch.bmm(a, v).transpose(0, 1).reshape(W * B, E) @ p["attention.out_proj.weight"].t() + p["attention.out_proj.bias"]
+    o = o.reshape(W, B, E)
+    x = o.reshape(-1, W, E)                                   # the reference's .view(-1, W, E): a re-interpretation, not a transpose
+    x = torch.relu((x * p["conv_1.weight"].reshape(1, W, 1)).sum(1) + p["conv_1.bias"])      # Conv1d(W -> 1, 1): [B, E]
+    h = x @ p["fc_2.weight"].t() + p["fc_2.bias"]
+    h = torch.relu(batchnorm_rows(h, p["bn_2.weight"], p["bn_2.bias"], bufs, "bn_2.", train))
+    return h @ p["fc_3.weight"].t() + p["fc_3.bias"], a.reshape(B, heads, W, W).mean(1)
+
+
 def loss_terms(logits, targets_pc, t_feat, class_w=(1.0, 2.0, 2.0, 1.0, 1.0)):
     """(ce, reg): weighted CE with ignore_index -1, mean over non-ignored weights; Frobenius norm of
     I - F F^T over the whole [B, 64, 64] tensor (train_pointnet-attention.py:127,138,445,463-464)."""

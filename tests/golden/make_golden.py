@@ -399,7 +399,42 @@ def sec_gru():
     save("gru", **res)
 
 
-SECTIONS = dict(gru=sec_gru, baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
+def sec_cls():
+    """f4: ClassificationWithAttention (pointnetAtt.py:115-151): eval forward (with a key-padding mask) and a train-mode forward +
+    backward of a cross-entropy on its output with dropout 0 (constructor argument): output, attention weights, every gradient."""
+    from pointNet.model.pointnetAtt import ClassificationWithAttention
+    Wn, B, C = 5, 16, 3
+    table = P.cls_head_params(C, Wn)
+    net = ClassificationWithAttention(256, 8, num_classes=C, dropout=0.0, num_w=Wn)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(9, table).items()}
+    sd.update({k: torch.from_numpy(v) for k, v in synth.make_buffers(9, P.CLS_HEAD_BUFFERS).items()})
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+    assert list(dict(net.named_parameters()).keys()) == list(table.keys())
+    gl = torch.from_numpy(synth.uniform(91, (Wn, B, 256), 0.0, 2.0))
+    mask = torch.zeros(B, Wn, dtype=torch.bool)
+    mask[1, 3:] = True
+    mask[7, 4] = True
+    net.eval()
+    with torch.no_grad():
+        out, aw = net(gl, None, mask)
+    res = dict(meta=np.array([Wn, B, C]), eval_out=out.numpy(), eval_weights=aw.numpy())
+    net.train()
+    glg = gl.clone().requires_grad_(True)
+    out, aw = net(glg, None, mask)
+    tgt = torch.from_numpy(synth.randint(92, (B,), 0, C))
+    loss = torch.nn.functional.cross_entropy(out, tgt)
+    loss.backward()
+    res.update(train_out=out.detach().numpy(), train_weights=aw.detach().numpy(), loss=loss.detach().numpy(), d_gl=glg.grad.numpy())
+    for k, p_ in net.named_parameters():
+        res[f"grad/{k}"] = p_.grad.numpy()
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            res[f"buf/{k}"] = v.numpy()
+    save("cls", **res)
+
+
+SECTIONS = dict(cls=sec_cls, gru=sec_gru, baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
                 collate=sec_collate, dataset=sec_dataset, baseline=sec_baseline)
 
 if __name__ == "__main__":
