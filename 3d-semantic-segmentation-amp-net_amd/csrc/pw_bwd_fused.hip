@@ -212,10 +212,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         if (more && w_role) load_regs(nxt);
         const float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
         if (w_role && SYM) {
+            // Ten tiles over four waves would be 3, 3, 2, 2 per k step (48 / 32 MFMAs per block of rows next to the D wave's 64 on the same
+            // SIMD: the workgroup runs at the pace of the 112).  The diagonal tiles (1,1) and (3,3) are therefore split over the rows:
+            // waves 0 / 1 take them for the first half of the k steps, waves 2 / 3 (which read that column block anyway) for the
+            // second half into an accumulator of their own, added at the flush: 40 MFMAs per wave and block of rows.
             const float *gc0 = g + 32 * sym_b0 + r, *gc1 = g + 32 * sym_b1 + r, *gc2 = g + 32 * sym_b2 + r;
+            constexpr int HALF = ROWS / 4;
             if (sym3) {
                 float c0_n = gc0[h * LDG], c1_n = gc1[h * LDG];
-#pragma unroll 8
+#pragma unroll
                 for (int s2 = 0; s2 < ROWS / 2; ++s2) {
                     const float c0 = c0_n, c1 = c1_n;
                     if (s2 + 1 < ROWS / 2) {
@@ -225,12 +230,12 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                     __builtin_amdgcn_sched_barrier(0);
                     acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c0, acc_w[0][0], 0, 0, 0);
                     acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c1, acc_w[0][1], 0, 0, 0);
-                    acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c1, acc_w[1][0], 0, 0, 0);
+                    if (s2 < HALF) acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c1, acc_w[1][0], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 float c0_n = gc0[h * LDG], c1_n = gc1[h * LDG], c2_n = gc2[h * LDG];
-#pragma unroll 8
+#pragma unroll
                 for (int s2 = 0; s2 < ROWS / 2; ++s2) {
                     const float c0 = c0_n, c1 = c1_n, c2 = c2_n;
                     if (s2 + 1 < ROWS / 2) {
@@ -238,9 +243,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                         c1_n = gc1[(2 * s2 + 2 + h) * LDG];
                         c2_n = gc2[(2 * s2 + 2 + h) * LDG];
                     }
+                    const float cd = ww == 2 ? c1 : c2;                // wave 2 helps tile (1,1), wave 3 tile (3,3)
                     __builtin_amdgcn_sched_barrier(0);
                     acc_w[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, c2, acc_w[0][0], 0, 0, 0);
                     acc_w[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c2, acc_w[0][1], 0, 0, 0);
+                    if (s2 >= HALF) acc_w[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cd, cd, acc_w[1][0], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -358,6 +365,20 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     }
 
     // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
+    if (SYM) {
+        // the second-half partials of the diagonal tiles (waves 2, 3) join the first halves (waves 0, 1); the staged tiles are consumed
+        float *xch = sG;                                       // [2][16][64]
+        if (w_role && !sym3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[((ww - 2) * 16 + e) * 64 + lane] = acc_w[1][0][e];
+        }
+        __syncthreads();
+        if (w_role && sym3) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_w[1][0][e] += xch[(ww * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
+    }
     if (w_role && SYM) {
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
 #pragma unroll
