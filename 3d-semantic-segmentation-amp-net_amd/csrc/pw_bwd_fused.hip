@@ -297,12 +297,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                     addv[e] = rr < valid ? a.add[(size_t)(trow0 + rr) * CY + dcol] : 0.f;
                 }
             }
-            f32x16 acc0, acc1;
+            // one accumulator, started at the per-slot bias: dependent fp32 MFMAs issue back to back at full rate (scratch/mfma_probe2.hip),
+            // and every add saved in the epilogue is matrix-pipe time (VALU does not overlap with fp32 MFMA here)
+            f32x16 acc0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc0[e] = 0.f;
-                acc1[e] = 0.f;
-            }
+            for (int e = 0; e < 16; ++e) acc0[e] = c_b;
             const float *ga = g + (32 * rt + r) * LDG + 4 * h;
             const float *wb = sWt + dcol * LDG + 4 * h;
             f32x4 g0 = *reinterpret_cast<const f32x4 *>(ga), w0 = *reinterpret_cast<const f32x4 *>(wb);
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cg0[i], cw0[i], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cg1[i], cw1[i], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cg1[i], cw1[i], acc0, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                     const bool ok = FULL || rr < valid;
-                    float v = acc0[e] + acc1[e] + c_b;
+                    float v = acc0[e];
                     if (ADD) v += addv[e];
                     if (YACT) {
                         if (DROP) {
