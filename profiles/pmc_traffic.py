@@ -44,7 +44,7 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None):
     for key, v in res.items():
         sym, grid = key.split("|grid=")
         name = None
-        m = re.match(r"ampnet::pw_gemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)>", sym)
+        m = re.match(r"ampnet::pw_gemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)[,>]", sym)   # <CIN, NT, PRO, POOL, BF, ...>
         if m:
             name = f"pw_gemm<{m.group(1)},{32 * int(m.group(2))}>" + ("+pool" if m.group(4) == "true" else "+store") + (" bf16" if m.group(5) == "true" else "")
         m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false)", sym)

@@ -1,4 +1,4 @@
-"""Run N fused train steps only (for rocprofv3 --kernel-trace --stats): python3 scratch/prof_step.py [steps]"""
+"""Run N fused train steps only (for rocprofv3 --kernel-trace --stats): python3 scratch/prof_step.py [steps] [precision]"""
 import importlib, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,8 @@ synth = importlib.import_module(PKG + ".synthetic")
 M = importlib.import_module(PKG + ".pointNet.model.pointnetAtt")
 T = importlib.import_module(PKG + ".trainer")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if len(sys.argv) > 2:
+    importlib.import_module(PKG + "._lib").set_matrix_precision(sys.argv[2])     # fp32 | bf16 | bf16_train | bf16_store
 B, W, N = 64, 9, 2048
 enc = M.BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=256, device="cuda")
 att = M.SegmentationWithAttention(256, 8, num_classes=5, local_dim=64, device="cuda")
