@@ -42,6 +42,15 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi)
 
 constexpr int PW_NW = 4;   // waves per workgroup
 
+// 1 / x for x >= 1 to ~1e-16 relative: hardware estimate + two Newton steps (x0 (2 - d x0))
+__device__ __forceinline__ double rcp_f64(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = x * __builtin_fma(-d, x, 2.0);
+    x = x * __builtin_fma(-d, x, 2.0);
+    return x;
+}
+
 __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major)
 {
     return slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
@@ -184,7 +193,10 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const int ntiles = (nrows + 31) / 32;
     // A fragments: blocks of 4 j (= 32 k = one 128-byte line per row), the next block prefetched in registers
     // while the current one feeds 16 * NT MFMAs.  The prefetch runs across tile boundaries.
-    f32x4 a_cur[4], a_nxt[4];
+    f32x4 a_cur[4], a_nxt[4], a_nx2[4];
+    // bf16 kernels: the matrix work of a 32-k block is 8 MFMAs of 32 cycles, far shorter than a trip to HBM, so ONE block in flight per
+    // wave caps the kernel at bytes-in-flight / latency (about 4 TB/s measured); they keep TWO blocks in flight (a_nxt, a_nx2)
+    constexpr int PF = BF ? 2 : 1;
 
     auto frag_ptr = [&](int tile, int kb) -> const float * {
         const int row0 = row_begin + tile * 32;
@@ -213,6 +225,14 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     };
     int tile = wave;
     if (tile < ntiles) load_frags(a_cur, tile, 0);
+    if (PF == 2) {                                        // prime the second stage: block 1 of this tile, or block 0 of the wave's next tile
+        int ptile = tile, pkb = 1;
+        if (pkb >= NBLK) {
+            ptile += PW_NW;
+            pkb = 0;
+        }
+        if (ptile < ntiles) load_frags(a_nxt, ptile, pkb);
+    }
     auto pro_apply = [&](f32x4 v, const f32x4 &sc, const f32x4 &sh, int row, int k0) -> f32x4 {
         if (PRO) {
 #pragma unroll
@@ -260,12 +280,12 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         for (int kb = 0; kb < NBLK; ++kb) {
             // prefetch the next block (same tile, or block 0 of this wave's next tile)
             {
-                int ptile = tile, pkb = kb + 1;
-                if (pkb == NBLK) {
-                    ptile = tile + PW_NW;
-                    pkb = 0;
+                int ptile = tile, pkb = kb + PF;
+                while (pkb >= NBLK) {
+                    ptile += PW_NW;
+                    pkb -= NBLK;
                 }
-                if (ptile < ntiles) load_frags(a_nxt, ptile, pkb);
+                if (ptile < ntiles) load_frags(PF == 2 ? a_nx2 : a_nxt, ptile, pkb);
             }
             if (BF) {
 #pragma unroll
@@ -378,7 +398,10 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[t][i], acc[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+            for (int j = 0; j < 4; ++j) {
+                a_cur[j] = a_nxt[j];
+                if (PF == 2) a_nxt[j] = a_nx2[j];
+            }
         }
 
         if (a.variant & 1) __builtin_amdgcn_s_setprio(0);
@@ -491,12 +514,16 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         for (int w = 0; w < PW_NW; ++w) {
             const double nw = (double)red_n[w];
             if (do_stats && nw > 0.0) {
+                // reciprocals of the (small integer) row counts by v_rcp_f64 + two Newton steps instead of four IEEE divisions per
+                // wave: this merge sits between two barriers, i.e. on every wave's critical path (28 % of a bf16 block of rows)
                 const double s1 = red_f[(w * CB + c) * 4 + 0], s2 = red_f[(w * CB + c) * 4 + 1];
-                const double mw = (double)red_f[(w * CB + c) * 4 + 3] + s1 / nw;
-                const double m2w = s2 - s1 * s1 / nw;
-                const double nn = n + nw, delta = mw - mean;
-                mean += delta * nw / nn;
-                m2 += m2w + delta * delta * n * nw / nn;
+                const double nn = n + nw;
+                const double inv_nw = rcp_f64(nw), inv_nn = rcp_f64(nn);
+                const double mw = (double)red_f[(w * CB + c) * 4 + 3] + s1 * inv_nw;
+                const double m2w = s2 - s1 * s1 * inv_nw;
+                const double delta = mw - mean, wgt = nw * inv_nn;
+                mean += delta * wgt;
+                m2 += m2w + delta * delta * n * wgt;
                 n = nn;
             }
             const float ve = red_f[(w * CB + c) * 4 + 2];

@@ -7,7 +7,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in base new base new; do
   if [ $v = base ]; then export AMPNET_LIB_PATH=$GRAFT_REPO_ROOT/scratch/lib_base.so; else unset AMPNET_LIB_PATH; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v.$RANDOM -o r -- python3 $GRAFT_REPO_ROOT/scratch/prof_step.py 6 > $O/log_$v.txt 2>&1 || { tail -5 $O/log_$v.txt; exit 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v.$RANDOM -o r -- python3 $GRAFT_REPO_ROOT/scratch/prof_step.py 6 ${3:-fp32} > $O/log_$v.txt 2>&1 || { tail -5 $O/log_$v.txt; exit 1; }
 done
 cd $GRAFT_REPO_ROOT
 for d in $O/base.* $O/new.*; do echo "$d"; python3 scratch/step_stats.py $d/r_kernel_stats.csv 0; grep -E "$PAT" $d/r_kernel_stats.csv | awk -F'",' '{print "   ", $2, $1}' | cut -c1-170; done
