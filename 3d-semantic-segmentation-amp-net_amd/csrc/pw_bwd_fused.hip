@@ -47,6 +47,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
     constexpr bool x_act = GRAM, has_bn = !GRAM, same = GRAM, y_act = YACT;
+    // SACT: the layer's input activation relu(bn(z_{l-1})) is applied ONCE while the tile is staged and sZ holds a = relu(z s + t): the four
+    // weight-gradient waves used to recompute it for every k step (2 VALU per MFMA, and VALU time is matrix-pipe time here); the
+    // data-gradient role gets its ReLU mask as a > 0 and zhat = (z - mean) invstd = (a - beta) / gamma where the mask holds
+    constexpr bool SACT = YACT && !GRAM && !DROP;
 
     // ---- work split: items = (window of this slot, chunk of FB_ITEM_ROWS rows), contiguous share per workgroup ----
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
@@ -82,6 +86,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     if (has_bn || x_act) {
         p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
         p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
+    }
+    f32x4 ys4 = {1.f, 1.f, 1.f, 1.f}, yt4 = {0.f, 0.f, 0.f, 0.f};
+    if (SACT) {
+        ys4 = *reinterpret_cast<const f32x4 *>(a.prev.s + (size_t)slot * CY + 4 * cqy);
+        yt4 = *reinterpret_cast<const f32x4 *>(a.prev.t + (size_t)slot * CY + 4 * cqy);
     }
 
     // ---- the walk over blocks of ROWS rows (crosses item boundaries so that the prefetch never drains) ----
@@ -152,7 +161,14 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         }
         if (!same) {
 #pragma unroll
-            for (int i = 0; i < NIY; ++i) *reinterpret_cast<f32x4 *>(z + (rsy + SY * i) * LDZ + 4 * cqy) = ry_z[i];
+            for (int i = 0; i < NIY; ++i) {
+                f32x4 zv4 = ry_z[i];
+                if (SACT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) zv4[c] = fmaxf(fmaf(zv4[c], ys4[c], yt4[c]), 0.f);
+                }
+                *reinterpret_cast<f32x4 *>(z + (rsy + SY * i) * LDZ + 4 * cqy) = zv4;
+            }
         }
     };
 
@@ -191,6 +207,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const float c_t = y_act ? a.prev.t[(size_t)slot * CY + dcol] : 0.0f;
     const float c_m = (y_act && a.prev_mean) ? a.prev_mean[(size_t)slot * CY + dcol] : 0.0f;
     const float c_i = (y_act && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_beta = fmaf(c_m, c_s, c_t);                      // t = beta - mean s
+    const float c_invg = c_s != 0.f ? c_i / c_s : 0.f;             // gamma = s / invstd; gamma = 0: P2 = 0, any finite zhat will do
     const bool do_part = a.part_a != nullptr;
     float s_a = 0.f, s_b = 0.f;
     const uint32_t dthr = drop_threshold(a.prev.drop_p);
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 for (int i = 0; i < TXW; ++i) xa[i] = xa_n[i];
 #pragma unroll
                 for (int j = 0; j < TYW; ++j) {
-                    yb[j] = (y_act && !GRAM) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];
+                    yb[j] = (y_act && !GRAM && !SACT) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];
                     if (DROP) {
                         const uint32_t el = (uint32_t)(cur.row0 + kr) * (uint32_t)CY + (uint32_t)(32 * (ty0 + j) + r);
                         yb[j] = (mix32(el ^ a.prev.drop_seed) >= dthr) ? yb[j] * dscale : 0.f;
@@ -345,10 +363,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                             const uint32_t el = (uint32_t)(trow0 + rr) * (uint32_t)CY + (uint32_t)dcol;
                             v = (mix32(el ^ a.prev.drop_seed) >= dthr) ? v * dscale : 0.f;
                         }
-                        v = fmaf(zv[e], c_s, c_t) > 0.f ? v : 0.f;
+                        v = (SACT ? zv[e] : fmaf(zv[e], c_s, c_t)) > 0.f ? v : 0.f;
                         const float vs = ok ? v : 0.f;
                         s_a += vs;
-                        s_b = fmaf(vs, (zv[e] - c_m) * c_i, s_b);
+                        s_b = fmaf(vs, SACT ? (zv[e] - c_beta) * c_invg : (zv[e] - c_m) * c_i, s_b);
                     }
                     if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
                 }
