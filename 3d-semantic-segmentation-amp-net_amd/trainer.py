@@ -222,6 +222,10 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     else:
         d_lo, d_gl = ops.head_backward(hpt, hg.table, local, cent, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
                                        dlog, att_net._ws, att_net._bws)
+    # data parallel: the head's gradient buffer is complete here -- its all-reduce travels while the encoder backward runs
+    dist, world = _dist_world()
+    if world > 1:
+        _PENDING[id(hg.flat)] = dist.all_reduce(hg.flat, op=dist.ReduceOp.SUM, async_op=True)
     d_ft = torch.zeros_like(feat_T)
     ops.reg_loss_backward(feat_last, G, reg, reg_weight, d_ft[-B:])
     ops.encoder_backward(ept, eg.table, xr, off, Q, total, mx, W, local, feat_T, d_lo, d_gl, d_ft, pointnet._ws, pointnet._bws)
@@ -230,14 +234,22 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     return dict(logits=logits, preds=preds, ce=loss2, reg=reg, targets_pc=targets_pc, B=B, grad_bufs=(eg.flat, hg.flat))
 
 
+_PENDING = {}        # id(flat gradient buffer) -> work handle of an all-reduce forward_backward already started
+
+
 def reduce_gradients(grad_bufs, optimizers):
     """Data-parallel gradient exchange: ONE all-reduce (SUM) per network over its flat gradient buffer (4.8 MB in all,
     latency-bound on xGMI), the 1 / world_size average folded into FusedAdam's kernel (or applied to p.grad for other
-    optimisers).  No-op when torch.distributed is not initialised.  Returns the world size."""
+    optimisers).  An all-reduce forward_backward already started for a buffer (the head's, overlapped with the encoder backward) is
+    waited for here instead of being issued again.  No-op when torch.distributed is not initialised.  Returns the world size."""
     dist, world = _dist_world()
     if world > 1:
         for flat in grad_bufs:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            work = _PENDING.pop(id(flat), None)
+            if work is not None:
+                work.wait()
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         for opt in optimizers:
             if isinstance(opt, FusedAdam):
                 opt.grad_scale = 1.0 / world
