@@ -50,7 +50,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     // SACT: the layer's input activation relu(bn(z_{l-1})) is applied ONCE while the tile is staged and sZ holds a = relu(z s + t): the four
     // weight-gradient waves used to recompute it for every k step (2 VALU per MFMA, and VALU time is matrix-pipe time here); the
     // data-gradient role gets its ReLU mask as a > 0 and zhat = (z - mean) invstd = (a - beta) / gamma where the mask holds
-    constexpr bool SACT = YACT && !GRAM && !DROP;
+    // Gram form: sG already IS that activated tile (x and y are the same tensor), so the raw copy in sZ is not written at all.
+    constexpr bool SACT = YACT && !DROP;
 
     // ---- work split: items = (window of this slot, chunk of FB_ITEM_ROWS rows), contiguous share per workgroup ----
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
     }
     f32x4 ys4 = {1.f, 1.f, 1.f, 1.f}, yt4 = {0.f, 0.f, 0.f, 0.f};
-    if (SACT) {
+    if (SACT && !GRAM) {
         ys4 = *reinterpret_cast<const f32x4 *>(a.prev.s + (size_t)slot * CY + 4 * cqy);
         yt4 = *reinterpret_cast<const f32x4 *>(a.prev.t + (size_t)slot * CY + 4 * cqy);
     }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 dbacc += xv;
             }
             *reinterpret_cast<f32x4 *>(g + (rsx + SX * i) * LDG + 4 * cqx) = xv;
-            if (same) *reinterpret_cast<f32x4 *>(z + (rsx + SX * i) * LDZ + 4 * cqx) = rx_z[i];   // CX == CY here
+            if (same && !SACT) *reinterpret_cast<f32x4 *>(z + (rsx + SX * i) * LDZ + 4 * cqx) = rx_z[i];   // CX == CY here
         }
         if (!same) {
 #pragma unroll
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 for (int i = 0; i < TXW; ++i) xa[i] = xa_n[i];
 #pragma unroll
                 for (int j = 0; j < TYW; ++j) {
-                    yb[j] = (y_act && !GRAM && !SACT) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];
+                    yb[j] = (y_act && !GRAM && !SACT) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];   // DROP: the raw tile + mask
                     if (DROP) {
                         const uint32_t el = (uint32_t)(cur.row0 + kr) * (uint32_t)CY + (uint32_t)(32 * (ty0 + j) + r);
                         yb[j] = (mix32(el ^ a.prev.drop_seed) >= dthr) ? yb[j] * dscale : 0.f;
@@ -346,7 +347,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             float zv[16];
             if (YACT) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) zv[e] = z[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+                for (int e = 0; e < 16; ++e)
+                    zv[e] = (GRAM && SACT) ? g[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * LDG + dcol] : z[(32 * rt + (e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
             }
             // one base pointer per lane, compile-time row offsets: the stores need no per-element address arithmetic
             float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
