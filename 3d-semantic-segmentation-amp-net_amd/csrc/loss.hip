@@ -118,3 +118,37 @@ extern "C" int ampnet_ce_bwd_f32(const float *logits, const long long *targets, 
                        loss2, grad_scale, B, C, P, dlogits);
     return check_launch("ce_bwd_kernel");
 }
+
+// ---- a11 on the device: confusion counts of one batch (utils/get_metrics.py:6-31 are quotients of these) ---------------------------
+namespace ampnet {
+constexpr int CONF_MAX_C = 8;
+__global__ __launch_bounds__(256) void confusion_kernel(const long long *__restrict__ preds, const long long *__restrict__ targets, long long n, int C,
+                                                       unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned int h[CONF_MAX_C * CONF_MAX_C + 1];
+    for (int i = threadIdx.x; i <= C * C; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long t = targets[i], p = preds[i];
+        if (t < 0 || t >= C || p < 0 || p >= C) atomicAdd(&h[C * C], 1u);          // ignored (-1 = padding)
+        else atomicAdd(&h[(int)t * C + (int)p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= C * C; i += blockDim.x)
+        if (h[i]) atomicAdd(&counts[i], (unsigned long long)h[i]);                  // integer: order-independent, exact
+}
+}  // namespace ampnet
+
+extern "C" int ampnet_confusion_i64(const long long *preds, const long long *targets, long long n, int n_classes, long long *counts, void *stream)
+{
+    AMPNET_REQUIRE(preds && targets && counts, "ampnet_confusion_i64: null pointer");
+    AMPNET_REQUIRE(n >= 0 && n_classes >= 1 && n_classes <= ampnet::CONF_MAX_C, "ampnet_confusion_i64: n=%lld classes=%d", n, n_classes);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, (size_t)(n_classes * n_classes + 1) * sizeof(long long), st) != hipSuccess)
+        return ampnet::fail(AMPNET_E_LAUNCH, "ampnet_confusion_i64: memset failed");
+    if (n == 0) return AMPNET_OK;
+    const int blocks = (int)((n + 256LL * 16 - 1) / (256LL * 16)) < 1024 ? (int)((n + 256LL * 16 - 1) / (256LL * 16)) : 1024;
+    hipLaunchKernelGGL(ampnet::confusion_kernel, dim3(blocks), dim3(256), 0, st, preds, targets, n, n_classes,
+                       reinterpret_cast<unsigned long long *>(counts));
+    return ampnet::check_launch("confusion_kernel");
+}

@@ -113,9 +113,11 @@ def _class_weights(ce_loss, device):
 
 
 def train_loop(data, optimizer_pointnet, optimizer_att, ce_loss, pointnet, att_net,
-               w_tensorboard=None, task='classification', train=True, epoch=0, last_epoch=0, first_batch_val=False):
+               w_tensorboard=None, task='classification', train=True, epoch=0, last_epoch=0, first_batch_val=False, device_outputs=False):
     """Drop-in for the reference's train_loop (segmentation task).
-    Returns (metrics {'ce_loss', 'reg_loss', 'loss'}, targets_pc [B, W*N] cpu, preds [B, W*N] cpu, last_epoch)."""
+    Returns (metrics {'ce_loss', 'reg_loss', 'loss'}, targets_pc [B, W*N] cpu, preds [B, W*N] cpu, last_epoch).
+    device_outputs=True (not in the reference): targets and predictions stay on the GPU and nothing synchronises -- for drivers that
+    take their metrics on the device (utils.get_metrics.confusion_device)."""
     if task != 'segmentation':
         raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
     from .. import ops
@@ -141,6 +143,8 @@ def train_loop(data, optimizer_pointnet, optimizer_att, ce_loss, pointnet, att_n
     metrics['ce_loss'] = out["ce"][0].view(-1, 1)
     metrics['reg_loss'] = out["reg"]
     metrics['loss'] = metrics['ce_loss'] + 0.001 * metrics['reg_loss'] if train else metrics['ce_loss']
+    if device_outputs:
+        return metrics, out["targets_pc"].to(dev), out["preds"], last_epoch
     return metrics, _download(out["targets_pc"], 0), _download(out["preds"], 1), last_epoch
 
 

@@ -42,8 +42,35 @@ def _dist_setup():
 
 
 def _epoch(loader, train, pointnet, att_net, opt_p, opt_a, ce_loss, epoch):
+    """One pass over the loader.  Default: predictions and targets never leave the GPU -- per batch one confusion-count kernel and four
+    scalars stay queued on the device and are downloaded ONCE at the end of the epoch, so no step synchronises with the host (the
+    reference downloads both tensors every step and takes accuracy / IoU with numpy, train_pointnet-attention.py:217-240).
+    AMPNET_HOST_METRICS=1 or AMPNET_HOST_AUG=1: the reference's per-step host path."""
     sums = dict(loss=[], ce=[], reg=[], acc=[])
     ious = {k: [] for k in IOU_NAMES}
+    dev = next(pointnet.parameters()).device
+    on_device = os.environ.get("AMPNET_HOST_AUG") != "1" and os.environ.get("AMPNET_HOST_METRICS") != "1"
+    if on_device:
+        from ..utils.get_metrics import confusion_device, metrics_from_confusion
+        from .prefetch import DevicePrefetcher
+        counts, scalars = [], []
+        for data in DevicePrefetcher(loader, dev):                # batch i + 1 uploads while step i computes
+            metrics, targets, preds, _ = train_loop(data, opt_p, opt_a, ce_loss, pointnet, att_net, None, 'segmentation', train, epoch, 0,
+                                                    device_outputs=True)
+            counts.append(confusion_device(preds, targets, len(IOU_NAMES)))
+            scalars.append(torch.stack([metrics['loss'].reshape(()), metrics['ce_loss'].reshape(()), metrics['reg_loss'].reshape(())]))
+        if counts:
+            counts_h = torch.stack(counts).cpu().numpy()
+            scalars_h = torch.stack(scalars).cpu().numpy()
+            for c, sc in zip(counts_h, scalars_h):
+                acc, per = metrics_from_confusion(c, len(IOU_NAMES))
+                sums['acc'].append(acc)
+                for name, v in zip(IOU_NAMES, per):
+                    ious[name].append(v)
+                sums['loss'].append(float(sc[0]))
+                sums['ce'].append(float(sc[1]))
+                sums['reg'].append(float(sc[2]))
+        return reduce_epoch_metrics(sums, ious, device=dev)
     for data in loader:
         metrics, targets, preds, _ = train_loop(data, opt_p, opt_a, ce_loss, pointnet, att_net, None, 'segmentation', train, epoch, 0)
         preds, targets, _ = rm_padding(preds.reshape(-1), targets.reshape(-1))
@@ -53,7 +80,7 @@ def _epoch(loader, train, pointnet, att_net, opt_p, opt_a, ce_loss, epoch):
         sums['loss'].append(metrics['loss'].item())
         sums['ce'].append(metrics['ce_loss'].item())
         sums['reg'].append(metrics['reg_loss'].item())
-    return reduce_epoch_metrics(sums, ious, device=next(pointnet.parameters()).device)
+    return reduce_epoch_metrics(sums, ious, device=dev)
 
 
 def reduce_epoch_metrics(sums, ious, device=None):

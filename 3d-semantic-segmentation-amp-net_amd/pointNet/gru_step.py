@@ -53,7 +53,7 @@ def forward_batch(pointnet, gru_model, x, t, class_w=None, want_loss=True, want_
 
 
 def train_loop(data, optimizer_rnn, optimizer_pred, ce_loss, pointnet, gru_model, w_tensorboard=None, task='classification', train=True,
-               c_weights=None, epoch=0, last_epoch=0, first_batch_val=False):
+               c_weights=None, epoch=0, last_epoch=0, first_batch_val=False, device_outputs=False):
     """Drop-in for the reference's train_loop (segmentation task; its classification branch never assigns `logits`,
     train_pointnetGRU.py:405-407, i.e. it cannot run there either).
     Returns (metrics {'ce_loss', 'reg_loss', 'loss'}, targets_pc [B, W*N] cpu, preds [B, W*N] cpu, last_epoch)."""
@@ -78,4 +78,6 @@ def train_loop(data, optimizer_rnn, optimizer_pred, ce_loss, pointnet, gru_model
     metrics['ce_loss'] = out["ce"][0].view(-1, 1)
     metrics['reg_loss'] = out["reg"]
     metrics['loss'] = metrics['ce_loss'] + 0.001 * metrics['reg_loss'] if train else metrics['ce_loss']
+    if device_outputs:                        # not in the reference: nothing leaves the GPU, nothing synchronises (amp_step.train_loop)
+        return metrics, out["targets_pc"], out["preds"], last_epoch
     return metrics, _download(out["targets_pc"], 0), _download(out["preds"], 1), last_epoch

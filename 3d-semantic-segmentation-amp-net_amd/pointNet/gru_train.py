@@ -16,7 +16,7 @@ import torch
 
 from ..trainer import FusedAdam
 from ..utils.get_metrics import get_accuracy, get_iou_obj
-from ..utils.utils import get_labels, kmeans_clustering, rm_padding, save_checkpoint_segmen_model
+from ..utils.utils import get_labels, kmeans_clustering, save_checkpoint_segmen_model
 from .amp_train import IOU_NAMES, reduce_epoch_metrics
 from .collate_fns import collate_seq_padd
 from .datasets import LidarDataset4Test, LidarKmeansDataset
@@ -29,18 +29,29 @@ CLASS_KEYS = ['bckg', 'tower', 'cables', 'low_veg', 'high_veg']
 
 
 def _epoch(loader, train, pointnet, pred_net, opt_p, opt_g, ce_loss, epoch):
+    """As amp_train._epoch: prefetched uploads, predictions stay on the device, confusion counts per step, one download per epoch."""
+    from ..utils.get_metrics import confusion_device, metrics_from_confusion
+    from .prefetch import DevicePrefetcher
     sums = dict(loss=[], ce=[], reg=[], acc=[])
     ious = {k: [] for k in IOU_NAMES}
-    for data in loader:
-        metrics, targets, preds, _ = train_loop(data, opt_p, opt_g, ce_loss, pointnet, pred_net, None, 'segmentation', train, None, epoch, 0)
-        preds, targets, _ = rm_padding(preds.reshape(-1), targets.reshape(-1))
-        sums['acc'].append(get_accuracy(preds, targets, {}, 'segmentation')['accuracy'])
-        for c, name in enumerate(IOU_NAMES):
-            ious[name].append(get_iou_obj(preds, targets, c))
-        sums['loss'].append(metrics['loss'].item())
-        sums['ce'].append(metrics['ce_loss'].item())
-        sums['reg'].append(metrics['reg_loss'].item())
-    return reduce_epoch_metrics(sums, ious, device=next(pointnet.parameters()).device)
+    dev = next(pointnet.parameters()).device
+    counts, scalars = [], []
+    for data in DevicePrefetcher(loader, dev):
+        metrics, targets, preds, _ = train_loop(data, opt_p, opt_g, ce_loss, pointnet, pred_net, None, 'segmentation', train, None, epoch, 0,
+                                                device_outputs=True)
+        counts.append(confusion_device(preds, targets, len(IOU_NAMES)))
+        scalars.append(torch.stack([metrics['loss'].reshape(()), metrics['ce_loss'].reshape(()), metrics['reg_loss'].reshape(())]))
+    if counts:
+        counts_h, scalars_h = torch.stack(counts).cpu().numpy(), torch.stack(scalars).cpu().numpy()
+        for c, sc in zip(counts_h, scalars_h):
+            acc, per = metrics_from_confusion(c, len(IOU_NAMES))
+            sums['acc'].append(acc)
+            for name, v in zip(IOU_NAMES, per):
+                ious[name].append(v)
+            sums['loss'].append(float(sc[0]))
+            sums['ce'].append(float(sc[1]))
+            sums['reg'].append(float(sc[2]))
+    return reduce_epoch_metrics(sums, ious, device=dev)
 
 
 def train_gru(task, dataset_folder, path_list_files, output_folder, n_points, n_windows, batch_size, epochs, learning_rate,

@@ -213,6 +213,13 @@ int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *re
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 
+/* ---- a11 on the device: the counts behind get_accuracy / get_iou_obj (utils/get_metrics.py:6-31) ----------------------------------
+ * counts[t * C + p] = number of points with target t and prediction p, counts[C * C] = number of ignored points (target -1 = padding,
+ * what rm_padding removes, utils/utils.py:14-19); counts is WRITTEN ([C * C + 1] int64).  accuracy = trace / kept; IoU of label c =
+ * counts[c][c] / (row sum c + column sum c - counts[c][c]).  Lets a training driver keep predictions on the device: no 2 x 9.4 MB
+ * download and no synchronisation per step.                                                                                      */
+int ampnet_confusion_i64(const long long *preds, const long long *targets, long long n, int n_classes, long long *counts, void *stream);
+
 /* ---- a8 on the device: the input pipeline of train_loop in one kernel --------------------------------------------
  * replaces the host augmentation of train_pointnet-attention.py:390-405 (shuffle_clusters utils/utils.py:620-632,
  * rotate_point_cloud_z :582-604, shuffle_data :607-617) and the [B, N, 9, W] -> [B, W, N, 9] re-layout.
