@@ -215,3 +215,37 @@ def test_gru_reference_style_loop_with_autograd_and_dropout(golden, synth, param
             if err > 3.0 * noise + 2e-4 * float(w.norm()) + 1e-5 * gtot + 1.5 * kink[(tag, k)]:
                 bad.append((tag, k, err / (float(w.norm()) + 1e-30), noise / (float(w.norm()) + 1e-30)))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,sizes", [(1, [7]), (1, [33, 1, 100]), (3, [5, 64, 31, 257]), (2, [2048] * 2 + [100] * 16)])
+def test_gru_head_edge_shapes_match_oracle(synth, params, B, sizes):
+    """Ragged / tiny / many windows (W = 1 .. 18, window sizes that are no multiple of the 32-row tiles) through the reference-signature
+    forward in eval mode and one train-mode forward + backward, against the oracle."""
+    from oracle import ampnet_oracle as O
+    _, gru = _models(synth, params, 5, 6, p_drop=0.0)
+    W, P = len(sizes), sum(sizes)
+    seq = torch.from_numpy(synth.uniform(81, (B, W, 256), 0.0, 2.0))
+    lo = torch.from_numpy(synth.uniform(82, (B, P, 64), -1.0, 1.0))
+    hp = torch_params(synth.make_params(6, params.GRU_HEAD_PARAMS))
+    hb = torch_params(synth.make_buffers(6, params.HEAD_BUFFERS))
+    gru.eval()
+    with torch.no_grad():
+        got = gru(seq.cuda(), lo.cuda(), sizes)
+    want = O.gru_head(hp, hb, seq, lo, sizes, train=False)
+    assert got.shape == (B, 5, P)
+    assert (got.cpu() - want).abs().max().item() <= 1e-3
+    if B * P >= 8:                                             # a BatchNorm over a handful of rows is not a meaningful gradient test
+        gru.train()
+        s2, l2 = seq.cuda().requires_grad_(True), lo.cuda().requires_grad_(True)
+        out = gru(s2, l2, sizes)
+        tgt = torch.from_numpy(synth.randint(83, (B, P), 0, 5)).cuda()
+        torch.nn.functional.cross_entropy(out, tgt).backward()
+        p64 = {k: v.double().requires_grad_(True) for k, v in hp.items()}
+        b64 = {k: v.double() for k, v in hb.items()}
+        s64, l64 = seq.double().requires_grad_(True), lo.double().requires_grad_(True)
+        o64 = O.gru_head(p64, b64, s64, l64, sizes, train=True)
+        torch.nn.functional.cross_entropy(o64, tgt.cpu()).backward()
+        assert (out.detach().double().cpu() - o64.detach()).abs().max().item() <= 2e-3
+        for got_g, want_g, name in ((s2.grad, s64.grad, "global_seq"), (l2.grad, l64.grad, "local_feats")):
+            err = float((got_g.double().cpu() - want_g).norm()) / (float(want_g.norm()) + 1e-12)
+            assert err <= 2e-2, (name, err)
