@@ -51,7 +51,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     // weight-gradient waves used to recompute it for every k step (2 VALU per MFMA, and VALU time is matrix-pipe time here); the
     // data-gradient role gets its ReLU mask as a > 0 and zhat = (z - mean) invstd = (a - beta) / gamma where the mask holds
     // Gram form: sG already IS that activated tile (x and y are the same tensor), so the raw copy in sZ is not written at all.
-    constexpr bool SACT = YACT && !DROP;
+    // DROP (dropout on that activation): the staged value is the DROPPED activation a' = keep ? a / (1 - p) : 0 -- the hash of the element
+    // index is taken once per element here instead of once per k step in four waves plus once per output element; a' > 0 is ReLU mask
+    // and keep mask in one, a = a' (1 - p) where it holds.
+    constexpr bool SACT = YACT;
 
     // ---- work split: items = (window of this slot, chunk of FB_ITEM_ROWS rows), contiguous share per workgroup ----
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
@@ -88,6 +91,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
         p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
         p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
     }
+    const uint32_t dthr = drop_threshold(a.prev.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.prev.drop_p) : 1.0f;
     f32x4 ys4 = {1.f, 1.f, 1.f, 1.f}, yt4 = {0.f, 0.f, 0.f, 0.f};
     if (SACT && !GRAM) {
         ys4 = *reinterpret_cast<const f32x4 *>(a.prev.s + (size_t)slot * CY + 4 * cqy);
@@ -167,6 +172,11 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 if (SACT) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) zv4[c] = fmaxf(fmaf(zv4[c], ys4[c], yt4[c]), 0.f);
+                    if (DROP) {
+                        const uint32_t e0 = (uint32_t)(p.row0 + rsy + SY * i) * (uint32_t)CY + (uint32_t)(4 * cqy);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) zv4[c] = (mix32((e0 + c) ^ a.prev.drop_seed) >= dthr) ? zv4[c] * dscale : 0.f;
+                    }
                 }
                 *reinterpret_cast<f32x4 *>(z + (rsy + SY * i) * LDZ + 4 * cqy) = zv4;
             }
@@ -210,11 +220,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const float c_i = (y_act && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
     const float c_beta = fmaf(c_m, c_s, c_t);                      // t = beta - mean s
     const float c_invg = c_s != 0.f ? c_i / c_s : 0.f;             // gamma = s / invstd; gamma = 0: P2 = 0, any finite zhat will do
+    const float c_undrop = DROP ? 1.0f - a.prev.drop_p : 1.0f;     // a = a' (1 - p) for a kept element
     const bool do_part = a.part_a != nullptr;
     float s_a = 0.f, s_b = 0.f;
-    const uint32_t dthr = drop_threshold(a.prev.drop_p);
-    const float dscale = DROP ? 1.0f / (1.0f - a.prev.drop_p) : 1.0f;
-
     Pos cur, nxt;
     bool live = open_item(item_begin, cur);
     if (live && w_role) load_regs(cur);
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
                 for (int j = 0; j < TYW; ++j) {
                     yb[j] = (y_act && !GRAM && !SACT) ? fmaxf(fmaf(yb_n[j], wys[j], wyt[j]), 0.f) : yb_n[j];   // DROP: the raw tile + mask
-                    if (DROP) {
+                    if (DROP && !SACT) {
                         const uint32_t el = (uint32_t)(cur.row0 + kr) * (uint32_t)CY + (uint32_t)(32 * (ty0 + j) + r);
                         yb[j] = (mix32(el ^ a.prev.drop_seed) >= dthr) ? yb[j] * dscale : 0.f;
                     }
@@ -361,14 +369,15 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                     float v = acc0[e];
                     if (ADD) v += addv[e];
                     if (YACT) {
-                        if (DROP) {
+                        if (DROP && !SACT) {
                             const uint32_t el = (uint32_t)(trow0 + rr) * (uint32_t)CY + (uint32_t)dcol;
                             v = (mix32(el ^ a.prev.drop_seed) >= dthr) ? v * dscale : 0.f;
                         }
+                        if (DROP && SACT) v *= dscale;                       // kept elements only survive the mask below
                         v = (SACT ? zv[e] : fmaf(zv[e], c_s, c_t)) > 0.f ? v : 0.f;
                         const float vs = ok ? v : 0.f;
                         s_a += vs;
-                        s_b = fmaf(vs, SACT ? (zv[e] - c_beta) * c_invg : (zv[e] - c_m) * c_i, s_b);
+                        s_b = fmaf(vs, SACT ? (zv[e] * c_undrop - c_beta) * c_invg : (zv[e] - c_m) * c_i, s_b);
                     }
                     if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
                 }
