@@ -43,7 +43,6 @@ struct PwGemm {
     int chunks = 1;                // cdiv(max window rows, chunk_rows)
     long rows_hint = 0;            // total rows (profiling only: algorithmic flops / bytes of the launch)
     int a_bf16 = 0, z_bf16 = 0;    // A / Z are bf16 tensors ([rows, lda] / [rows, ldz] ELEMENTS): activation storage of precision mode 3
-    int variant = 0;               // experiment knob (AMPNET_PW_VARIANT): bit 0 = wave priority raised in the K loop, bit 1 = epilogue skipped (timing only)
 };
 int pw_gemm(const PwGemm &a, hipStream_t st);
 // one element of an activation tensor that is fp32 or (precision mode 3) bf16

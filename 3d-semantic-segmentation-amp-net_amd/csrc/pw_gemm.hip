@@ -272,7 +272,6 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = init_v[t];
 
-        if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
         // the pipelined fp32 loop is unrolled over its k blocks: the LDS offsets of the operand reads become immediates
         // (25 integer VALU instructions per block of 64 MFMAs otherwise -- and VALU time is matrix-pipe time here)
         constexpr int KB_UNROLL = (PIPE && !BF && CIN <= 128) ? NBLK : 1;
@@ -404,11 +403,6 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             }
         }
 
-        if (a.variant & 1) __builtin_amdgcn_s_setprio(0);
-        if (a.variant & 2) {
-            if (acc[0][0] == 123.456f) s_cnt += 1;            // keeps the MFMAs alive
-            continue;
-        }
         // ---- epilogue: lane = output channel, registers = 16 rows; predicated, no branch between elements ----
         if (do_stats) {
             if (tile == wave) {
@@ -616,10 +610,8 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
     return pro ? launch_pw_x<CIN, NT, 1, false>(a, st) : launch_pw_x<CIN, NT, 0, false>(a, st);
 }
 
-int pw_gemm(const PwGemm &a_in, hipStream_t st)
+int pw_gemm(const PwGemm &a, hipStream_t st)
 {
-    PwGemm a = a_in;
-    if (const char *ve = getenv("AMPNET_PW_VARIANT")) a.variant = atoi(ve);
     AMPNET_REQUIRE(a.A && a.W && a.win_off, "pw_gemm: null pointer");
     AMPNET_REQUIRE(a.Q >= 1 && a.chunks >= 1 && a.cout >= 1, "pw_gemm: bad sizes Q=%d chunks=%d cout=%d", a.Q, a.chunks, a.cout);
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
