@@ -208,8 +208,9 @@ struct SgProblem {
     const float *A, *B;
     float *C;
 };
+constexpr int SG_MAX_PROBLEMS = 10;
 struct SgArgs {
-    SgProblem p[2];      // blockIdx.z picks the problem: independent products of one backward step share a launch
+    SgProblem p[SG_MAX_PROBLEMS];      // blockIdx.z picks the problem: independent products of one backward step share a launch
 };
 
 __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
 
 static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
 {
+    AMPNET_REQUIRE(n >= 1 && n <= SG_MAX_PROBLEMS, "sgemm_small: %d problems", n);
     SgArgs a;
     int gx = 1, gy = 1;
     double flops = 0.0, bytes = 0.0;
@@ -325,6 +327,23 @@ int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, con
 {
     const SgProblem p[2] = {{n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW}, {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX}};
     return sgemm_launch(p, 2, st);
+}
+
+// the same for a layer with thousands of outputs (the feature T-Net's fc_3: 128 -> 4096): dX = G W has few output tiles and a K of n_out, so
+// one workgroup per tile walks 128 k tiles in sequence (114 us for 1.2 GFLOP).  The K range is cut into `splits` problems of the same
+// launch, each writing its own partial [rows, n_in]; a fixed-order reduction adds them (no atomics: reproducible).
+int sgemm_linear_bwd_ksplit(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW,
+                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st)
+{
+    AMPNET_REQUIRE(scratch && splits >= 2 && splits < SG_MAX_PROBLEMS && n_out % splits == 0, "sgemm_linear_bwd_ksplit: %d outputs in %d splits", n_out, splits);
+    SgProblem p[SG_MAX_PROBLEMS];
+    p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
+    const int kc = n_out / splits;
+    for (int c = 0; c < splits; ++c)
+        p[1 + c] = {rows, n_in, kc, 0, 0, ldg, ldw, n_in, 0, G + (size_t)c * kc, W + (size_t)c * kc * ldw, scratch + (size_t)c * rows * n_in};
+    int rc = sgemm_launch(p, 1 + splits, st);
+    if (rc != AMPNET_OK) return rc;
+    return reduce_windows(scratch, splits, (long)rows * n_in, rows, n_in, n_in, dX, lddx, 0, st);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@ struct EncBwdWs {
     float *wpart, *dbpart;     // [Q, 256 * 128], [Q, 256]
     float *dpm;                // [Q, 256] masked pooled gradient
     float *a1, *a2, *da2, *g2, *da1, *g1, *d_pool;   // FC: [Q,256] [Q,128] [Q,128] [Q,128] [Q,256] [Q,256] [Q,256]
+    float *fc_split;                                 // [8, Q, 128] K-split partials of the 4096-output fc_3 data gradient
     float *dT64, *dT64t;       // [Q, 4096]
     float *dWeff, *dT3;        // [Q, 576], [Q, 12]
     float *srows, *Gm, *c0, *gram, *asum;   // [Q*256,128] [S,128,128] [S,128] [S,128,128] [S,128]: pooled-layer algebra
@@ -65,6 +66,7 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.a1 = c.take<float>(Q * 256);
     w.a2 = c.take<float>(Q * 128);
     w.da2 = c.take<float>(Q * 128);
+    w.fc_split = c.take<float>(8 * Q * 128);
     w.g2 = c.take<float>(Q * 128);
     w.da1 = c.take<float>(Q * 256);
     w.g1 = c.take<float>(Q * 256);
@@ -323,7 +325,10 @@ struct EncBwd {
         TRY(fc_act(zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, Q, 256, per, b.a1, st));
         TRY(fc_act(zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, Q, 128, per, b.a2, st));
         // fc_3: z3 = a2 W3^T + b3
-        TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st));
+        if (kk >= 1024)
+            TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st));
+        else
+            TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st));
         TRY(colsum(g3, Q, kk, G[pbase + TP_FC3_B], st));
         TRY(fc_bn_bwd(b.da2, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per, 128, b.g2,
                       b.bn[bn0 + 4].slot_ab, st));

@@ -382,5 +382,8 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
 // backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
                      float *dX, int lddx, hipStream_t st);
+// n_out in the thousands: dX's K range split over `splits` problems of the launch + a fixed-order reduction; scratch [splits, rows, n_in]
+int sgemm_linear_bwd_ksplit(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW,
+                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st);
 
 }  // namespace ampnet
