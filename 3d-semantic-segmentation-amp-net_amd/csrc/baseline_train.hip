@@ -24,12 +24,13 @@ struct TGrad {                 // gradients of the same (nullptr where the layer
 
 struct Dims {
     int k, G, F1, F2, H1, H2, H3;
+    int C1, C2;                // ClassificationPointNet: fc_1 G -> C1, fc_2 C1 -> C2 (pointnet.py:109-111, light_pointnet_256.py:109-111)
 };
 
 bool dims_for(int variant, Dims *d)
 {
-    if (variant == 0) *d = Dims{3, 1024, 512, 256, 512, 256, 128};
-    else if (variant == 1) *d = Dims{2, 256, 256, 128, 256, 128, 64};
+    if (variant == 0) *d = Dims{3, 1024, 512, 256, 512, 256, 128, 512, 256};
+    else if (variant == 1) *d = Dims{2, 256, 256, 128, 256, 128, 64, 128, 64};
     else return false;
     return true;
 }
@@ -238,6 +239,53 @@ __global__ void bt_add_kernel(float *__restrict__ y, const float *__restrict__ x
     if (i < n) y[i] += x[i];
 }
 
+// eval mode: the "batch statistics" of a layer are its running statistics
+__global__ void bt_running_stats_kernel(const float *__restrict__ rm, const float *__restrict__ rv, int C, float eps, float *__restrict__ mean,
+                                        float *__restrict__ invstd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mean[c] = rm[c];
+        invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+    }
+}
+
+// nn.Dropout(p) on a [n] tensor: out = keep(i) ? a * 1 / (1 - p) : 0 with the package's counter hash (kernels.h: mix32; the oracle's keep_mask);
+// the backward is the same map on the gradient
+__global__ void bt_dropout_kernel(const float *__restrict__ a, size_t n, uint32_t base, uint32_t thr, float scale, float *__restrict__ out)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (mix32((uint32_t)i ^ base) >= thr) ? a[i] * scale : 0.f;
+}
+
+// F.log_softmax(z, dim=1) on [B, C] (C <= 64): one thread per row
+__global__ void bt_log_softmax_kernel(const float *__restrict__ z, int B, int C, float *__restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -__builtin_inff();
+    for (int c = 0; c < C; ++c) m = fmaxf(m, z[(size_t)b * C + c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[(size_t)b * C + c] - m);
+    const float lse = m + logf(s);
+    for (int c = 0; c < C; ++c) out[(size_t)b * C + c] = z[(size_t)b * C + c] - lse;
+}
+
+// backward of log_softmax: dz = d_out - softmax(z) * sum_c d_out
+__global__ void bt_log_softmax_bwd_kernel(const float *__restrict__ z, const float *__restrict__ d_out, int B, int C, float *__restrict__ dz)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -__builtin_inff(), tot = 0.f;
+    for (int c = 0; c < C; ++c) {
+        m = fmaxf(m, z[(size_t)b * C + c]);
+        tot += d_out[(size_t)b * C + c];
+    }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[(size_t)b * C + c] - m);
+    for (int c = 0; c < C; ++c) dz[(size_t)b * C + c] = d_out[(size_t)b * C + c] - expf(z[(size_t)b * C + c] - m) / s * tot;
+}
+
 #define BT_TRY(expr)                      \
     do {                                  \
         int rc_ = (expr);                 \
@@ -256,13 +304,16 @@ struct Rec {                   // one linear (+ BatchNorm + ReLU) layer on the t
 struct Ws {
     Rec L[AMPNET_POINTNET_LAYERS];
     float *xin, *pool_i, *pool_f, *pool_c, *T3, *T64, *local, *gb;
+    float *a_drop;             // classification head: dropout(relu(bn_2(fc_2))) [B, C2]
+    int n_layers;
     int *arg_i, *arg_f, *arg_c;
     // backward scratch
     float *dA, *dB, *d_local, *d_c2, *d_pool, *d_gb, *dT64, *dT3, *d_xin, *dgs, *dbs;
     size_t bytes;
 };
 
-void carve(const Dims &d, int B, int N, int C, void *base, Ws &w)
+// cls: the 20-layer classification model (17 base layers + fc_1, fc_2, fc_3 on the global feature) instead of the 21-layer segmentation model
+void carve(const Dims &d, int B, int N, int C, void *base, Ws &w, bool cls = false)
 {
     size_t off = 0;
     auto take = [&](size_t n_floats) {
@@ -272,12 +323,19 @@ void carve(const Dims &d, int B, int N, int C, void *base, Ws &w)
     };
     const size_t R = (size_t)B * N;
     const int kk = d.k * d.k;
-    const int couts[AMPNET_POINTNET_LAYERS] = {64, 128, d.G, d.F1, d.F2, kk, 64, 128, d.G, d.F1, d.F2, 4096, 64, 64, 64, 128, d.G, d.H1, d.H2, d.H3, C};
-    const int Ks[AMPNET_POINTNET_LAYERS] = {d.k, 64, 128, d.G, d.F1, d.F2, 64, 64, 128, d.G, d.F1, d.F2, 9, 64, 64, 64, 128, 64, d.H1, d.H2, d.H3};
-    const bool point[AMPNET_POINTNET_LAYERS] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-    const bool bn[AMPNET_POINTNET_LAYERS] = {1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0};
+    int couts[AMPNET_POINTNET_LAYERS] = {64, 128, d.G, d.F1, d.F2, kk, 64, 128, d.G, d.F1, d.F2, 4096, 64, 64, 64, 128, d.G, d.H1, d.H2, d.H3, C};
+    int Ks[AMPNET_POINTNET_LAYERS] = {d.k, 64, 128, d.G, d.F1, d.F2, 64, 64, 128, d.G, d.F1, d.F2, 9, 64, 64, 64, 128, 64, d.H1, d.H2, d.H3};
+    bool point[AMPNET_POINTNET_LAYERS] = {1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    bool bn[AMPNET_POINTNET_LAYERS] = {1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0};
+    w.n_layers = cls ? AMPNET_POINTNET_CLS_LAYERS : AMPNET_POINTNET_LAYERS;
+    if (cls) {
+        couts[17] = d.C1; couts[18] = d.C2; couts[19] = C;
+        Ks[17] = d.G; Ks[18] = d.C1; Ks[19] = d.C2;
+        point[17] = point[18] = point[19] = false;
+        bn[17] = bn[18] = true; bn[19] = false;
+    }
     int maxc = 64;
-    for (int i = 0; i < AMPNET_POINTNET_LAYERS; ++i) {
+    for (int i = 0; i < w.n_layers; ++i) {
         Rec &r = w.L[i];
         r.M = point[i] ? (int)R : B;
         r.K = Ks[i];
@@ -297,6 +355,7 @@ void carve(const Dims &d, int B, int N, int C, void *base, Ws &w)
     w.T64 = take((size_t)B * 4096);
     w.local = take(R * 64);
     w.gb = take((size_t)B * d.H1);
+    w.a_drop = take((size_t)B * d.C2);
     w.dA = take(R * maxc); w.dB = take(R * maxc);
     w.d_local = take(R * 64); w.d_c2 = take(R * 64);
     w.d_pool = take((size_t)B * d.G); w.d_gb = take((size_t)B * d.H1);
@@ -311,6 +370,7 @@ struct Ctx {
     const TLayer *L;
     const TGrad *G;
     Ws *w;
+    bool running = false;      // eval mode: BatchNorm with the running statistics (no update)
 };
 
 // forward of layer i: z = A[:, :K] W[:, w0 : w0 + K]^T + b (+ add[row / per]); statistics; activation
@@ -322,7 +382,8 @@ int fwd_layer(const Ctx &c, int i, const float *A, int lda, int ldw, int w0, con
     const size_t n = (size_t)r.M * r.cout;
     if (l.b || add) hipLaunchKernelGGL(bt_bias_kernel, dim3(nb(n)), dim3(256), 0, c.st, r.z, n, r.cout, l.b, add, per > 0 ? per : 1);
     if (l.g) {
-        hipLaunchKernelGGL(bt_stats_kernel, dim3(cdiv(r.cout, 64)), dim3(256), 0, c.st, r.z, r.M, r.cout, 1e-5f, 0.1f, r.mean, r.invstd, l.rm, l.rv);
+        if (c.running) hipLaunchKernelGGL(bt_running_stats_kernel, dim3(cdiv(r.cout, 256)), dim3(256), 0, c.st, l.rm, l.rv, r.cout, 1e-5f, r.mean, r.invstd);
+        else hipLaunchKernelGGL(bt_stats_kernel, dim3(cdiv(r.cout, 64)), dim3(256), 0, c.st, r.z, r.M, r.cout, 1e-5f, 0.1f, r.mean, r.invstd, l.rm, l.rv);
         hipLaunchKernelGGL(bt_bn_act_kernel, dim3(nb(n)), dim3(256), 0, c.st, r.z, n, r.cout, r.mean, r.invstd, l.g, l.be, r.a);
     }
     return check_launch("baseline train layer forward");
@@ -377,9 +438,9 @@ int tnet_bwd(const Ctx &c, const Dims &d, int base, float *dT, const float *A, i
     return bwd_layer(c, base + 0, w.dA, A, lda, k, 0, d_in, ld_in, 1);
 }
 
-int read_tables(const float *const *layers_host, float *const *grads_host, TLayer *L, TGrad *G)
+int read_tables(const float *const *layers_host, float *const *grads_host, TLayer *L, TGrad *G, int n_layers = AMPNET_POINTNET_LAYERS)
 {
-    for (int i = 0; i < AMPNET_POINTNET_LAYERS; ++i) {
+    for (int i = 0; i < n_layers; ++i) {
         const float *const *p = layers_host + 6 * i;
         L[i] = TLayer{p[0], p[1], p[2], p[3], const_cast<float *>(p[4]), const_cast<float *>(p[5])};
         AMPNET_REQUIRE(L[i].W, "baseline PointNet: layer %d has no weight", i);
@@ -391,6 +452,53 @@ int read_tables(const float *const *layers_host, float *const *grads_host, TLaye
         }
     }
     return AMPNET_OK;
+}
+
+// layers 0 .. 16 of both models (BasePointNet.forward up to the max-pool, pointnet.py:66-90): leaves local, pool_c / arg_c, T64 on the tape
+int base_fwd(const Ctx &c, const Dims &d, const float *x, int B, int N)
+{
+    Ws &w = *c.w;
+    const int R = B * N, k = d.k;
+    BT_TRY(tnet_fwd(c, d, 0, x, 9, k, B, N, w.pool_i, w.arg_i, w.T3));
+    hipLaunchKernelGGL(bt_mix_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.st, x, w.T3, R, N, k, w.xin);
+    BT_TRY(fwd_layer(c, 12, w.xin, 9, 9, 0, nullptr, 0));
+    BT_TRY(fwd_layer(c, 13, w.L[12].a, 64, 64, 0, nullptr, 0));
+    BT_TRY(tnet_fwd(c, d, 6, w.L[13].a, 64, 64, B, N, w.pool_f, w.arg_f, w.T64));
+    for (int b = 0; b < B; ++b)
+        BT_TRY(sgemm_small(0, 0, N, 64, 64, w.L[13].a + (size_t)b * N * 64, 64, w.T64 + (size_t)b * 4096, 64, w.local + (size_t)b * N * 64, 64, 0, c.st));
+    BT_TRY(fwd_layer(c, 14, w.local, 64, 64, 0, nullptr, 0));
+    BT_TRY(fwd_layer(c, 15, w.L[14].a, 64, 64, 0, nullptr, 0));
+    BT_TRY(fwd_layer(c, 16, w.L[15].a, 128, 128, 0, nullptr, 0));
+    hipLaunchKernelGGL(bt_rowmax_kernel, dim3(cdiv(d.G, 64), B), dim3(256), 0, c.st, w.L[16].a, N, d.G, w.pool_c, w.arg_c);
+    return check_launch("baseline PointNet base forward");
+}
+
+// backward of the same given w.d_pool (gradient of the global feature) and, when local_accumulate, w.d_local (the segmentation head's
+// gradient of the local features); d_feat_T [B, 64, 64] or nullptr joins at the feature transform
+int base_bwd(const Ctx &c, const Dims &d, const float *x, int B, int N, const float *d_feat_T, int local_accumulate)
+{
+    Ws &w = *c.w;
+    const int k = d.k;
+    const size_t R = (size_t)B * N;
+    // ---- conv_5 .. conv_3 ----
+    hipLaunchKernelGGL(bt_fill_kernel, dim3(nb(R * d.G)), dim3(256), 0, c.st, w.dA, R * d.G, 0.f);
+    hipLaunchKernelGGL(bt_pool_scatter_kernel, dim3(nb((size_t)B * d.G)), dim3(256), 0, c.st, w.d_pool, w.arg_c, B, N, d.G, w.dA);
+    BT_TRY(bwd_layer(c, 16, w.dA, w.L[15].a, 128, 128, 0, w.dB, 128, 0));
+    BT_TRY(bwd_layer(c, 15, w.dB, w.L[14].a, 64, 64, 0, w.dA, 64, 0));
+    BT_TRY(bwd_layer(c, 14, w.dA, w.local, 64, 64, 0, w.d_local, 64, local_accumulate));                   // (+= the head's d_local)
+    // ---- local = a_c2 x T64: dT64 = a_c2^T d_local (+ reg-loss gradient), d_a_c2 = d_local T64^T ----
+    for (int b = 0; b < B; ++b) {
+        BT_TRY(sgemm_small(1, 0, 64, 64, N, w.L[13].a + (size_t)b * N * 64, 64, w.d_local + (size_t)b * N * 64, 64, w.dT64 + (size_t)b * 4096, 64, 0, c.st));
+        BT_TRY(sgemm_small(0, 1, N, 64, 64, w.d_local + (size_t)b * N * 64, 64, w.T64 + (size_t)b * 4096, 64, w.d_c2 + (size_t)b * N * 64, 64, 0, c.st));
+    }
+    if (d_feat_T) hipLaunchKernelGGL(bt_add_kernel, dim3(nb((size_t)B * 4096)), dim3(256), 0, c.st, w.dT64, d_feat_T, (size_t)B * 4096);
+    BT_TRY(tnet_bwd(c, d, 6, w.dT64, w.L[13].a, 64, 64, B, N, w.pool_f, w.arg_f, w.d_c2, 64));             // += into d_a_c2
+    // ---- conv_2, conv_1 ----
+    BT_TRY(bwd_layer(c, 13, w.d_c2, w.L[12].a, 64, 64, 0, w.dA, 64, 0));
+    BT_TRY(bwd_layer(c, 12, w.dA, w.xin, 9, 9, 0, w.d_xin, 9, 0));
+    hipLaunchKernelGGL(bt_mix_bwd_kernel, dim3(B), dim3(256), 0, c.st, x, w.d_xin, N, k, w.dT3);
+    // ---- input T-Net (its input is x: no gradient needed) ----
+    return tnet_bwd(c, d, 0, w.dT3, x, 9, k, B, N, w.pool_i, w.arg_i, nullptr, 0);
 }
 
 }  // namespace
@@ -421,18 +529,8 @@ extern "C" int ampnet_pointnet_seg_train_fwd_f32(const float *const *layers_host
     TLayer L[AMPNET_POINTNET_LAYERS];
     BT_TRY(read_tables(layers_host, nullptr, L, nullptr));
     Ctx c{static_cast<hipStream_t>(stream), L, nullptr, &w};
-    const int R = B * N, k = d.k;
-    BT_TRY(tnet_fwd(c, d, 0, x, 9, k, B, N, w.pool_i, w.arg_i, w.T3));
-    hipLaunchKernelGGL(bt_mix_kernel, dim3(cdiv(R, 256)), dim3(256), 0, c.st, x, w.T3, R, N, k, w.xin);
-    BT_TRY(fwd_layer(c, 12, w.xin, 9, 9, 0, nullptr, 0));
-    BT_TRY(fwd_layer(c, 13, w.L[12].a, 64, 64, 0, nullptr, 0));
-    BT_TRY(tnet_fwd(c, d, 6, w.L[13].a, 64, 64, B, N, w.pool_f, w.arg_f, w.T64));
-    for (int b = 0; b < B; ++b)
-        BT_TRY(sgemm_small(0, 0, N, 64, 64, w.L[13].a + (size_t)b * N * 64, 64, w.T64 + (size_t)b * 4096, 64, w.local + (size_t)b * N * 64, 64, 0, c.st));
-    BT_TRY(fwd_layer(c, 14, w.local, 64, 64, 0, nullptr, 0));
-    BT_TRY(fwd_layer(c, 15, w.L[14].a, 64, 64, 0, nullptr, 0));
-    BT_TRY(fwd_layer(c, 16, w.L[15].a, 128, 128, 0, nullptr, 0));
-    hipLaunchKernelGGL(bt_rowmax_kernel, dim3(cdiv(d.G, 64), B), dim3(256), 0, c.st, w.L[16].a, N, d.G, w.pool_c, w.arg_c);
+    const int R = B * N;
+    BT_TRY(base_fwd(c, d, x, B, N));
     const int ldw = d.G + 64;
     BT_TRY(sgemm_small(0, 1, B, d.H1, d.G, w.pool_c, d.G, L[17].W, ldw, w.gb, d.H1, 0, c.st));
     BT_TRY(fwd_layer(c, 17, w.local, 64, ldw, d.G, w.gb, N));
@@ -460,7 +558,7 @@ extern "C" int ampnet_pointnet_seg_bwd_f32(const float *const *layers_host, floa
     TGrad G[AMPNET_POINTNET_LAYERS];
     BT_TRY(read_tables(layers_host, grads_host, L, G));
     Ctx c{static_cast<hipStream_t>(stream), L, G, &w};
-    const int k = d.k, ldw = d.G + 64;
+    const int ldw = d.G + 64;
     const size_t R = (size_t)B * N;
     // ---- segmentation head ----
     hipLaunchKernelGGL(bt_logits_kernel, dim3(nb(R * n_classes)), dim3(256), 0, c.st, w.dA, B, N, n_classes, const_cast<float *>(dlogits), 1);
@@ -472,24 +570,78 @@ extern "C" int ampnet_pointnet_seg_bwd_f32(const float *const *layers_host, floa
     hipLaunchKernelGGL(bt_segsum_kernel, dim3(cdiv(d.H1, 64), B), dim3(256), 0, c.st, w.dB, N, d.H1, w.d_gb);
     BT_TRY(sgemm_small(1, 0, d.H1, d.G, B, w.d_gb, d.H1, w.pool_c, d.G, G[17].dW, ldw, 0, c.st));          // dW[:, :G]
     BT_TRY(sgemm_small(0, 0, B, d.G, d.H1, w.d_gb, d.H1, L[17].W, ldw, w.d_pool, d.G, 0, c.st));           // d global feature
-    // ---- conv_5 .. conv_3 ----
-    hipLaunchKernelGGL(bt_fill_kernel, dim3(nb(R * d.G)), dim3(256), 0, c.st, w.dA, R * d.G, 0.f);
-    hipLaunchKernelGGL(bt_pool_scatter_kernel, dim3(nb((size_t)B * d.G)), dim3(256), 0, c.st, w.d_pool, w.arg_c, B, N, d.G, w.dA);
-    BT_TRY(bwd_layer(c, 16, w.dA, w.L[15].a, 128, 128, 0, w.dB, 128, 0));
-    BT_TRY(bwd_layer(c, 15, w.dB, w.L[14].a, 64, 64, 0, w.dA, 64, 0));
-    BT_TRY(bwd_layer(c, 14, w.dA, w.local, 64, 64, 0, w.d_local, 64, 1));                                  // += the head's d_local
-    // ---- local = a_c2 x T64: dT64 = a_c2^T d_local (+ reg-loss gradient), d_a_c2 = d_local T64^T ----
-    for (int b = 0; b < B; ++b) {
-        BT_TRY(sgemm_small(1, 0, 64, 64, N, w.L[13].a + (size_t)b * N * 64, 64, w.d_local + (size_t)b * N * 64, 64, w.dT64 + (size_t)b * 4096, 64, 0, c.st));
-        BT_TRY(sgemm_small(0, 1, N, 64, 64, w.d_local + (size_t)b * N * 64, 64, w.T64 + (size_t)b * 4096, 64, w.d_c2 + (size_t)b * N * 64, 64, 0, c.st));
-    }
-    if (d_feat_T) hipLaunchKernelGGL(bt_add_kernel, dim3(nb((size_t)B * 4096)), dim3(256), 0, c.st, w.dT64, d_feat_T, (size_t)B * 4096);
-    BT_TRY(tnet_bwd(c, d, 6, w.dT64, w.L[13].a, 64, 64, B, N, w.pool_f, w.arg_f, w.d_c2, 64));             // += into d_a_c2
-    // ---- conv_2, conv_1 ----
-    BT_TRY(bwd_layer(c, 13, w.d_c2, w.L[12].a, 64, 64, 0, w.dA, 64, 0));
-    BT_TRY(bwd_layer(c, 12, w.dA, w.xin, 9, 9, 0, w.d_xin, 9, 0));
-    hipLaunchKernelGGL(bt_mix_bwd_kernel, dim3(B), dim3(256), 0, c.st, x, w.d_xin, N, k, w.dT3);
-    // ---- input T-Net (its input is x: no gradient needed) ----
-    BT_TRY(tnet_bwd(c, d, 0, w.dT3, x, 9, k, B, N, w.pool_i, w.arg_i, nullptr, 0));
+    BT_TRY(base_bwd(c, d, x, B, N, d_feat_T, 1));
     return check_launch("ampnet_pointnet_seg_bwd_f32");
+}
+
+// ---- f4: ClassificationPointNet (pointnet.py:100-125, light_pointnet_256.py:100-125) on the same tape ---------------------------------
+extern "C" size_t ampnet_pointnet_cls_workspace_bytes(int variant, int B, int N, int n_classes)
+{
+    Dims d;
+    if (!dims_for(variant, &d) || B < 1 || N < 1 || n_classes < 1) return 0;
+    Ws w;
+    carve(d, B, N, n_classes, nullptr, w, true);
+    return w.bytes;
+}
+
+extern "C" int ampnet_pointnet_cls_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N, int n_classes, int train,
+                                           float drop_p, uint32_t seed, float *log_probs, float *feat_T, void *workspace, size_t workspace_bytes,
+                                           void *stream)
+{
+    Dims d;
+    AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_cls_fwd_f32: variant %d", variant);
+    AMPNET_REQUIRE(layers_host && x && log_probs && feat_T && workspace, "ampnet_pointnet_cls_fwd_f32: null pointer");
+    AMPNET_REQUIRE(B >= (train ? 2 : 1) && N >= 1 && n_classes >= 1 && n_classes <= 64 && (long long)B * N < (1LL << 24),
+                   "ampnet_pointnet_cls_fwd_f32: bad shape B=%d (train mode needs >= 2: batch statistics of the FC layers) N=%d classes=%d", B, N, n_classes);
+    AMPNET_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ampnet_pointnet_cls_fwd_f32: dropout p=%f", drop_p);
+    Ws w;
+    carve(d, B, N, n_classes, workspace, w, true);
+    AMPNET_REQUIRE(workspace_bytes >= w.bytes, "ampnet_pointnet_cls_fwd_f32: workspace %zu bytes, need %zu", workspace_bytes, w.bytes);
+    TLayer L[AMPNET_POINTNET_LAYERS];
+    BT_TRY(read_tables(layers_host, nullptr, L, nullptr, AMPNET_POINTNET_CLS_LAYERS));
+    Ctx c{static_cast<hipStream_t>(stream), L, nullptr, &w};
+    c.running = train == 0;
+    BT_TRY(base_fwd(c, d, x, B, N));
+    BT_TRY(fwd_layer(c, 17, w.pool_c, d.G, d.G, 0, nullptr, 0));
+    BT_TRY(fwd_layer(c, 18, w.L[17].a, d.C1, d.C1, 0, nullptr, 0));
+    const float *a2 = w.L[18].a;
+    if (train && drop_p > 0.f) {
+        const size_t n = (size_t)B * d.C2;
+        hipLaunchKernelGGL(bt_dropout_kernel, dim3(nb(n)), dim3(256), 0, c.st, a2, n, drop_base(seed, 0), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), w.a_drop);
+        a2 = w.a_drop;
+    }
+    BT_TRY(fwd_layer(c, 19, a2, d.C2, d.C2, 0, nullptr, 0));
+    hipLaunchKernelGGL(bt_log_softmax_kernel, dim3(cdiv(B, 64)), dim3(64), 0, c.st, w.L[19].z, B, n_classes, log_probs);
+    if (hipMemcpyAsync(feat_T, w.T64, (size_t)B * 4096 * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess)
+        return fail(AMPNET_E_LAUNCH, "ampnet_pointnet_cls_fwd_f32: copy of the feature transform failed");
+    return check_launch("ampnet_pointnet_cls_fwd_f32");
+}
+
+extern "C" int ampnet_pointnet_cls_bwd_f32(const float *const *layers_host, float *const *grads_host, int variant, const float *x, int B, int N,
+                                           int n_classes, float drop_p, uint32_t seed, const float *d_log_probs, const float *d_feat_T,
+                                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    Dims d;
+    AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_cls_bwd_f32: variant %d", variant);
+    AMPNET_REQUIRE(layers_host && grads_host && x && d_log_probs && workspace, "ampnet_pointnet_cls_bwd_f32: null pointer");
+    AMPNET_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ampnet_pointnet_cls_bwd_f32: dropout p=%f", drop_p);
+    Ws w;
+    carve(d, B, N, n_classes, workspace, w, true);
+    AMPNET_REQUIRE(workspace_bytes >= w.bytes, "ampnet_pointnet_cls_bwd_f32: workspace %zu bytes, need %zu", workspace_bytes, w.bytes);
+    TLayer L[AMPNET_POINTNET_LAYERS];
+    TGrad G[AMPNET_POINTNET_LAYERS];
+    BT_TRY(read_tables(layers_host, grads_host, L, G, AMPNET_POINTNET_CLS_LAYERS));
+    Ctx c{static_cast<hipStream_t>(stream), L, G, &w};
+    // log_softmax, fc_3 (its input is the dropped activation), dropout, fc_2, fc_1
+    hipLaunchKernelGGL(bt_log_softmax_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, c.st, w.L[19].z, d_log_probs, B, n_classes, w.dA);
+    const bool drop = drop_p > 0.f;
+    BT_TRY(bwd_layer(c, 19, w.dA, drop ? w.a_drop : w.L[18].a, d.C2, d.C2, 0, w.dB, d.C2, 0));
+    if (drop) {
+        const size_t n = (size_t)B * d.C2;
+        hipLaunchKernelGGL(bt_dropout_kernel, dim3(nb(n)), dim3(256), 0, c.st, w.dB, n, drop_base(seed, 0), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), w.dB);
+    }
+    BT_TRY(bwd_layer(c, 18, w.dB, w.L[17].a, d.C1, d.C1, 0, w.dA, d.C1, 0));
+    BT_TRY(bwd_layer(c, 17, w.dA, w.pool_c, d.G, d.G, 0, w.d_pool, d.G, 0));
+    BT_TRY(base_bwd(c, d, x, B, N, d_feat_T, 0));
+    return check_launch("ampnet_pointnet_cls_bwd_f32");
 }

@@ -38,6 +38,10 @@ struct ProfScope {
 // process-wide MFMA operand precision (ampnet_set_matrix_precision)
 int matrix_precision();
 
+// forward-workspace precision tags (core.hip): set by a train-mode forward, checked by its backward
+void ws_tag_set(const void *ws, int mode);
+int ws_tag_check(const void *ws, const char *who);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

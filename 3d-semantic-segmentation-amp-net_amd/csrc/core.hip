@@ -1,6 +1,8 @@
 // core.hip -- error plumbing and version entry points of the C ABI (include/ampnet_hip.h).
 #include "common.h"
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace ampnet {
@@ -95,6 +97,41 @@ extern "C" int ampnet_profile_read(int max_rows, char *names, double *ms, long l
 namespace ampnet {
 static int g_matrix_precision = AMPNET_PRECISION_F32;
 int matrix_precision() { return g_matrix_precision; }
+}  // namespace ampnet
+
+// ---- forward-workspace tags: which precision mode a train-mode forward ran in ------------------------------------------------
+// A backward entry point reads the forward's tape (the z tensors: fp32, or bf16 in mode 3) from the caller's workspace; the mode is
+// a process-wide switch that may change between the two calls (another model, a test fixture, autograd replay).  The forward records
+// (workspace base -> mode) on the host, the backward refuses a workspace whose forward ran in another mode instead of reinterpreting it.
+namespace ampnet {
+namespace {
+std::mutex g_tag_mu;
+std::unordered_map<const void *, int> g_ws_tag;
+}  // namespace
+void ws_tag_set(const void *ws, int mode)
+{
+    std::lock_guard<std::mutex> lk(g_tag_mu);
+    if (g_ws_tag.size() > 4096) g_ws_tag.clear();       // workspaces come and go with the caller's allocator: bounded
+    g_ws_tag[ws] = mode;
+}
+int ws_tag_check(const void *ws, const char *who)
+{
+    int have = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_tag_mu);
+        auto it = g_ws_tag.find(ws);
+        if (it != g_ws_tag.end()) have = it->second;
+    }
+    if (have < 0) return fail(AMPNET_E_ARG, "%s: this forward workspace holds no train-mode forward of this process", who);
+    // modes 0..2 keep the saved activations in fp32 (a backward in any of them may follow a forward in any of them: the operand rounding
+    // of the kernels differs, the tape does not); mode 3 keeps them in bf16
+    const int now = matrix_precision();
+    if ((have == AMPNET_PRECISION_BF16_STORE) != (now == AMPNET_PRECISION_BF16_STORE))
+        return fail(AMPNET_E_ARG, "%s: the forward ran in matrix precision mode %d, the backward is called in mode %d "
+                                  "(ampnet_set_matrix_precision changed in between): the saved activations (%s) would be misread", who, have, now,
+                    have == AMPNET_PRECISION_BF16_STORE ? "bf16" : "fp32");
+    return AMPNET_OK;
+}
 }  // namespace ampnet
 
 extern "C" int ampnet_set_matrix_precision(int mode)

@@ -270,6 +270,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     e.bind_bn();
     e.zb = z_storage_bf16();
     const bool tr = train != 0;
+    if (tr) ws_tag_set(workspace, matrix_precision());      // the backward checks it ran in the same precision mode
 
     TRY(fill_i32_ramp(e.ws.fc_off, e.s.n_slots + 1, e.s.fc_rows, e.st));
     if (!tr) {

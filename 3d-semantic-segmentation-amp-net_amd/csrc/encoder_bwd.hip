@@ -363,6 +363,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
 {
     AMPNET_REQUIRE(params_host && grads_host && x && win_off && local && d_global && feat_T && fwd_workspace && bwd_workspace, "ampnet_encoder_bwd_f32: null pointer");
     AMPNET_REQUIRE(Q >= 1 && n_slots >= 1 && Q % n_slots == 0, "ampnet_encoder_bwd_f32: Q=%d n_slots=%d", Q, n_slots);
+    TRY(ws_tag_check(fwd_workspace, "ampnet_encoder_bwd_f32"));
     EncBwd e;
     e.st = (hipStream_t)stream;
     e.s = enc_shape(Q, n_slots, total_rows, max_rows, 1);

@@ -113,7 +113,8 @@ __device__ __forceinline__ float min_f32(float a, float b)
 // fold and after the coordinate read of every round into a buffer nothing else reads.
 template <int T, int P, bool LDSXYZ, bool STAMP = false>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int n, int ld, int s,
-                                                int32_t *__restrict__ idx, unsigned long long *__restrict__ stamps = nullptr)
+                                                int32_t *__restrict__ idx, unsigned long long *__restrict__ stamps = nullptr,
+                                                const int *__restrict__ cloud_off = nullptr, const int *__restrict__ out_off = nullptr)
 {
     constexpr int NW = T / WAVE;
     static_assert(NW <= 16, "one row of 16 lanes folds the wave slots");
@@ -126,6 +127,16 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
     const int wave = tid / WAVE;
     const float *cloud = xyz + (size_t)blockIdx.x * n * ld;
     int32_t *out = idx + (size_t)blockIdx.x * s;
+    if (cloud_off) {
+        // ragged batch (ampnet_fps_ragged_f32): cloud b = rows cloud_off[b] .. cloud_off[b + 1] of one [total, ld] array, its samples go to
+        // idx[out_off[b] .. out_off[b + 1]); n <= T * P is the launcher's promise (the template is picked for the largest cloud)
+        const int c0 = cloud_off[blockIdx.x], o0 = out_off[blockIdx.x];
+        n = cloud_off[blockIdx.x + 1] - c0;
+        s = min(out_off[blockIdx.x + 1] - o0, n);
+        cloud = xyz + (size_t)c0 * ld;
+        out = idx + o0;
+        if (s <= 0) return;                          // uniform per workgroup
+    }
 
     // the P points of a thread as P / 2 PAIRS: differences, squares and the two sums are v_pk_add_f32 / v_pk_mul_f32 on a pair (correctly
     // rounded per element, so the distances stay bit-identical to numpy's) -- 8 instead of 16 VALU instructions per pair
@@ -228,13 +239,23 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
 // and the reduction carries 64-bit (distance, ~index) keys (lowest index on ties for any ownership).  A picked point is
 // retired by its owner during the next round's walk (its minimum becomes -1: every real distance is >= 0).
 template <int T>
-__global__ __launch_bounds__(T) void fps_stream_kernel(float *__restrict__ soa, int n, int s, int32_t *__restrict__ idx)
+__global__ __launch_bounds__(T) void fps_stream_kernel(float *__restrict__ soa, int n, int s, int32_t *__restrict__ idx,
+                                                       const int *__restrict__ cloud_off = nullptr, const int *__restrict__ out_off = nullptr)
 {
     __shared__ uint32_t s_hi[2][16], s_lo[2][16];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const float *X = soa + (size_t)blockIdx.x * 4 * n, *Y = X + n, *Z = Y + n;
-    float *D = soa + (size_t)blockIdx.x * 4 * n + 3 * (size_t)n;
+    size_t base = (size_t)blockIdx.x * 4 * n;
     int32_t *out = idx + (size_t)blockIdx.x * s;
+    if (cloud_off) {                                 // ragged batch: the workspace holds 4 * n_b floats per cloud, in cloud order
+        const int c0 = cloud_off[blockIdx.x], o0 = out_off[blockIdx.x];
+        n = cloud_off[blockIdx.x + 1] - c0;
+        s = min(out_off[blockIdx.x + 1] - o0, n);
+        base = (size_t)c0 * 4;
+        out = idx + o0;
+        if (s <= 0) return;
+    }
+    const float *X = soa + base, *Y = X + n, *Z = Y + n;
+    float *D = soa + base + 3 * (size_t)n;
     float lx = X[0], ly = Y[0], lz = Z[0];
     int last = 0;
     if (tid == 0) out[0] = 0;
@@ -282,12 +303,17 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(float *__restrict__ soa, 
 }
 
 // [n_clouds, n, ld] rows -> [n_clouds, 4, n] structure of arrays x, y, z, running minimum (the stream kernel's workspace)
-__global__ void fps_soa_kernel(const float *__restrict__ xyz, int n, int ld, float *__restrict__ soa)
+__global__ void fps_soa_kernel(const float *__restrict__ xyz, int n, int ld, float *__restrict__ soa, const int *__restrict__ cloud_off = nullptr)
 {
     const int c = blockIdx.y;
+    size_t row0 = (size_t)c * n;
+    if (cloud_off) {
+        row0 = (size_t)cloud_off[c];
+        n = cloud_off[c + 1] - cloud_off[c];
+    }
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        const float *p = xyz + ((size_t)c * n + j) * ld;
-        float *o = soa + (size_t)c * 4 * n;
+        const float *p = xyz + (row0 + j) * ld;
+        float *o = soa + row0 * 4;
         o[j] = p[0];
         o[n + j] = p[1];
         o[2 * (size_t)n + j] = p[2];
@@ -296,7 +322,8 @@ __global__ void fps_soa_kernel(const float *__restrict__ xyz, int n, int ld, flo
 }
 
 template <int T, int P>
-static int launch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, hipStream_t st)
+static int launch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, hipStream_t st, const int *cloud_off = nullptr,
+                  const int *out_off = nullptr)
 {
     const size_t lds = (size_t)n * 4 * sizeof(float);
     if (lds <= 144 * 1024) {
@@ -307,9 +334,9 @@ static int launch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t 
             if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "fps: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(n_clouds), dim3(T), lds, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(kern, dim3(n_clouds), dim3(T), lds, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr, cloud_off, out_off);
     } else {
-        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(n_clouds), dim3(T), 0, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(n_clouds), dim3(T), 0, st, xyz, n, ld, s, idx, (unsigned long long *)nullptr, cloud_off, out_off);
     }
     return check_launch("fps_kernel");
 }
@@ -335,6 +362,30 @@ extern "C" size_t ampnet_fps_workspace_bytes(int n_clouds, int n)
     return (size_t)n_clouds * 4 * (size_t)n * sizeof(float);
 }
 
+namespace ampnet {
+// n = points per cloud (uniform batch) or the LARGEST cloud of a ragged batch (cloud_off / out_off device arrays, n_clouds + 1 entries)
+static int fps_dispatch(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, float *soa, hipStream_t st, const int *cloud_off,
+                        const int *out_off)
+{
+    if (n > AMPNET_FPS_RESIDENT_MAX) {
+        hipLaunchKernelGGL(fps_soa_kernel, dim3(cdiv(n, 256) < 256 ? cdiv(n, 256) : 256, n_clouds), dim3(256), 0, st, xyz, n, ld, soa, cloud_off);
+        hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(n_clouds), dim3(1024), 0, st, soa, n, s, idx, cloud_off, out_off);
+        return check_launch("fps_stream_kernel");
+    }
+    if (n <= 256) return launch<256, 1>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+    if (n <= 1024) return launch<256, 4>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+    if (n <= 2048) return launch<512, 4>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+    if (n <= 4096) return launch<512, 8>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+    static const int t8k = [] { const char *e = getenv("AMPNET_FPS_T8K"); return e ? atoi(e) : 512; }();      // tuning hook
+    if (n <= 8192) {
+        if (t8k == 1024) return launch<1024, 8>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+        if (t8k == 768) return launch<768, 11>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+        return launch<512, 16>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+    }
+    return launch<1024, 16>(xyz, n_clouds, n, ld, s, idx, st, cloud_off, out_off);
+}
+}  // namespace ampnet
+
 extern "C" int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *workspace,
                               size_t workspace_bytes, void *stream)
 {
@@ -343,26 +394,33 @@ extern "C" int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int
     AMPNET_REQUIRE(n_clouds >= 1 && n >= 1 && ld >= 3, "ampnet_fps_f32: bad shape n_clouds=%d n=%d ld=%d", n_clouds, n, ld);
     AMPNET_REQUIRE(s >= 1 && s <= n, "ampnet_fps_f32: n_samples=%d must be in [1, n=%d]", s, n);
     AMPNET_REQUIRE(n <= AMPNET_FPS_MAX_POINTS, "ampnet_fps_f32: n=%d exceeds %d points per cloud", n, AMPNET_FPS_MAX_POINTS);
-    hipStream_t st = (hipStream_t)stream;
     if (n > AMPNET_FPS_RESIDENT_MAX) {
         const size_t need = ampnet_fps_workspace_bytes(n_clouds, n);
         if (!workspace || workspace_bytes < need) return fail(AMPNET_E_WORKSPACE, "ampnet_fps_f32: n=%d needs a workspace of %zu B (ampnet_fps_workspace_bytes)", n, need);
-        float *soa = reinterpret_cast<float *>(workspace);
-        hipLaunchKernelGGL(fps_soa_kernel, dim3(cdiv(n, 256) < 256 ? cdiv(n, 256) : 256, n_clouds), dim3(256), 0, st, xyz, n, ld, soa);
-        hipLaunchKernelGGL((fps_stream_kernel<1024>), dim3(n_clouds), dim3(1024), 0, st, soa, n, s, idx);
-        return check_launch("fps_stream_kernel");
     }
-    if (n <= 256) return launch<256, 1>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 1024) return launch<256, 4>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 2048) return launch<512, 4>(xyz, n_clouds, n, ld, s, idx, st);
-    if (n <= 4096) return launch<512, 8>(xyz, n_clouds, n, ld, s, idx, st);
-    static const int t8k = [] { const char *e = getenv("AMPNET_FPS_T8K"); return e ? atoi(e) : 512; }();      // tuning hook
-    if (n <= 8192) {
-        if (t8k == 1024) return launch<1024, 8>(xyz, n_clouds, n, ld, s, idx, st);
-        if (t8k == 768) return launch<768, 11>(xyz, n_clouds, n, ld, s, idx, st);
-        return launch<512, 16>(xyz, n_clouds, n, ld, s, idx, st);
+    return fps_dispatch(xyz, n_clouds, n, ld, s, idx, reinterpret_cast<float *>(workspace), (hipStream_t)stream, nullptr, nullptr);
+}
+
+extern "C" size_t ampnet_fps_ragged_workspace_bytes(int total_rows, int max_n)
+{
+    if (total_rows < 1 || max_n <= AMPNET_FPS_RESIDENT_MAX) return 0;
+    return (size_t)total_rows * 4 * sizeof(float);
+}
+
+extern "C" int ampnet_fps_ragged_f32(const float *rows, int ld, const int32_t *cloud_off, const int32_t *out_off, int n_clouds, int total_rows,
+                                     int max_n, int32_t *idx, void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace ampnet;
+    AMPNET_REQUIRE(rows && cloud_off && out_off && idx, "ampnet_fps_ragged_f32: null pointer");
+    AMPNET_REQUIRE(n_clouds >= 1 && ld >= 3 && max_n >= 1 && total_rows >= max_n, "ampnet_fps_ragged_f32: bad shape n_clouds=%d ld=%d max_n=%d total_rows=%d",
+                   n_clouds, ld, max_n, total_rows);
+    AMPNET_REQUIRE(max_n <= AMPNET_FPS_MAX_POINTS, "ampnet_fps_ragged_f32: max_n=%d exceeds %d points per cloud", max_n, AMPNET_FPS_MAX_POINTS);
+    if (max_n > AMPNET_FPS_RESIDENT_MAX) {
+        const size_t need = ampnet_fps_ragged_workspace_bytes(total_rows, max_n);
+        if (!workspace || workspace_bytes < need)
+            return fail(AMPNET_E_WORKSPACE, "ampnet_fps_ragged_f32: max_n=%d needs a workspace of %zu B (ampnet_fps_ragged_workspace_bytes)", max_n, need);
     }
-    return launch<1024, 16>(xyz, n_clouds, n, ld, s, idx, st);
+    return fps_dispatch(rows, n_clouds, max_n, ld, max_n, idx, reinterpret_cast<float *>(workspace), (hipStream_t)stream, cloud_off, out_off);
 }
 
 extern "C" int ampnet_fps_round_stamps(const float *xyz, int n, int ld, int s, int32_t *idx, unsigned long long *stamps, void *stream)
@@ -373,7 +431,7 @@ extern "C" int ampnet_fps_round_stamps(const float *xyz, int n, int ld, int s, i
     auto kern = fps_kernel<512, 16, true, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "fps: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(1), dim3(512), (size_t)n * 16, (hipStream_t)stream, xyz, n, ld, s, idx, stamps);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(512), (size_t)n * 16, (hipStream_t)stream, xyz, n, ld, s, idx, stamps, (const int *)nullptr, (const int *)nullptr);
     return check_launch("fps_kernel (stamps)");
 }
 

@@ -151,6 +151,7 @@ extern "C" int ampnet_gru_head_fwd_f32(const float *const *params_host, float *c
     const float *const *P = params_host;
     const bool tr = train != 0;
     const int Q = s.Q;
+    if (tr) ws_tag_set(workspace, matrix_precision());
 
     TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     auto tok_gemm = [&](const float *A, int cin, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
@@ -189,6 +190,7 @@ extern "C" int ampnet_gru_head_bwd_f32(const float *const *params_host, float *c
                    "ampnet_gru_head_bwd_f32: null pointer");
     AMPNET_REQUIRE(B >= 1 && W >= 1 && total_rows % B == 0, "ampnet_gru_head_bwd_f32: bad sizes");
     AMPNET_REQUIRE(n_classes >= 1 && n_classes <= HEAD_MAX_CLASSES, "ampnet_gru_head_bwd_f32: n_classes=%d", n_classes);
+    TRY(ws_tag_check(fwd_workspace, "ampnet_gru_head_bwd_f32"));
     hipStream_t st = (hipStream_t)stream;
     const HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, 1, HEAD_KIND_GRU);
     HeadWs f;

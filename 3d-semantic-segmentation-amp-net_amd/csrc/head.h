@@ -20,6 +20,7 @@ struct HeadShape {
     int kind;                      // which token producer feeds conv_2: attention (256-d token) or GRU (64-d hidden state)
     int chunk_rows, chunks;        // point layers
     int tok_chunk_rows, tok_chunks;   // token GEMMs: one window of Q rows
+    int logit_B;                   // the logits are [logit_B, C, R / logit_B]: B, or 1 for ampnet_head_fwd_files_f32
 };
 
 struct BnSlot1 {

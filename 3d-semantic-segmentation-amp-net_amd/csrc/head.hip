@@ -29,6 +29,7 @@ HeadShape head_shape(int B, int W, int R, int max_rows, int n_classes, int train
     s.chunks = cdiv(max_rows, s.chunk_rows);
     s.tok_chunk_rows = 128;
     s.tok_chunks = cdiv(s.Q, s.tok_chunk_rows);
+    s.logit_B = B;
     return s;
 }
 
@@ -98,7 +99,7 @@ int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, co
                     uint32_t seed, const HeadLossArgs &lo_, hipStream_t st)
 {
     const bool tr = s.train != 0;
-    const int Q = s.Q, B = s.B, total_rows = s.R, max_rows = s.max_rows, n_classes = s.n_classes;
+    const int Q = s.Q, total_rows = s.R, max_rows = s.max_rows, n_classes = s.n_classes;
     const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 are stored as bf16 (precision mode 3)
     if (!tr) {
         BnFoldItem items[2] = {{p.bn2_w, p.bn2_b, p.bn2_mean, p.bn2_var, ws.bn2.scale, ws.bn2.shift, 128},
@@ -143,7 +144,7 @@ int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, co
         o.z3 = ws.z3; o.scale = ws.bn3.scale; o.shift = ws.bn3.shift;
         o.W = p.conv4_w; o.bias = p.conv4_b;
         o.drop_p = dp; o.drop_seed = drop_base(seed, 2);
-        o.R = total_rows; o.P = total_rows / B; o.C = n_classes;
+        o.R = total_rows; o.P = total_rows / s.logit_B; o.C = n_classes;
         o.logits = lo_.logits; o.targets = lo_.targets; o.class_w = lo_.class_w; o.preds = lo_.preds;
         o.loss_part = lo_.loss_out ? ws.loss_part : nullptr;
         int blocks = 0;
@@ -177,21 +178,24 @@ extern "C" size_t ampnet_head_workspace_bytes(int B, int W, int total_rows, int 
     return ws.bytes;
 }
 
-extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl,
-                                   const float *lo, const float *centroids, const int32_t *win_off,
-                                   const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
-                                   int train, float drop_p, uint32_t seed, float *logits, const long long *targets,
-                                   const float *class_w, long long *preds, float *loss_out, void *workspace,
-                                   size_t workspace_bytes, void *stream)
+// logit_B: how many equal parts the rows are cut into for the [logit_B, C, P] logits / [logit_B, P] predictions: B for the module's
+// contract (every sample has the same number of points), 1 for the several-files-per-launch inference form (samples of unequal size)
+static int head_fwd_impl(const float *const *params_host, float *const *buffers_host, const float *gl,
+                         const float *lo, const float *centroids, const int32_t *win_off,
+                         const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
+                         int train, float drop_p, uint32_t seed, float *logits, const long long *targets,
+                         const float *class_w, long long *preds, float *loss_out, void *workspace,
+                         size_t workspace_bytes, void *stream, int logit_B)
 {
     AMPNET_REQUIRE(params_host && buffers_host && gl && lo && centroids && win_off && logits && workspace, "ampnet_head_fwd_f32: null pointer");
     AMPNET_REQUIRE(B >= 1 && W >= 1 && W <= HEAD_MAX_W, "ampnet_head_fwd_f32: B=%d W=%d (W <= %d)", B, W, HEAD_MAX_W);
-    AMPNET_REQUIRE(total_rows >= 1 && total_rows % B == 0, "ampnet_head_fwd_f32: total_rows %d not a multiple of B %d", total_rows, B);
+    AMPNET_REQUIRE(total_rows >= 1 && total_rows % logit_B == 0, "ampnet_head_fwd_f32: total_rows %d not a multiple of B %d", total_rows, logit_B);
     AMPNET_REQUIRE(n_classes >= 1 && n_classes <= HEAD_MAX_CLASSES, "ampnet_head_fwd_f32: n_classes=%d", n_classes);
     AMPNET_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ampnet_head_fwd_f32: dropout p=%f", drop_p);
     AMPNET_REQUIRE(!loss_out || targets, "ampnet_head_fwd_f32: loss_out needs targets");
     hipStream_t st = (hipStream_t)stream;
-    const HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, train);
+    HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, train);
+    s.logit_B = logit_B;
     HeadWs ws;
     head_carve(s, workspace, ws);
     if (ws.bytes > workspace_bytes) return fail(AMPNET_E_WORKSPACE, "ampnet_head_fwd_f32: workspace %zu B < %zu B", workspace_bytes, ws.bytes);
@@ -199,6 +203,7 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     const bool tr = train != 0;
     const float dp = tr ? drop_p : 0.f;
     const int Q = s.Q;
+    if (tr) ws_tag_set(workspace, matrix_precision());
 
     TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
@@ -224,4 +229,29 @@ extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const
     HeadLossArgs lo_args;
     lo_args.logits = logits; lo_args.targets = targets; lo_args.class_w = class_w; lo_args.preds = preds; lo_args.loss_out = loss_out;
     return head_points_fwd(s, ws, pp, lo, win_off, dp, seed, lo_args, st);
+}
+
+extern "C" int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl,
+                                   const float *lo, const float *centroids, const int32_t *win_off,
+                                   const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
+                                   int train, float drop_p, uint32_t seed, float *logits, const long long *targets,
+                                   const float *class_w, long long *preds, float *loss_out, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    return head_fwd_impl(params_host, buffers_host, gl, lo, centroids, win_off, key_pad_mask, B, W, total_rows, max_rows, n_classes, train, drop_p,
+                         seed, logits, targets, class_w, preds, loss_out, workspace, workspace_bytes, stream, B);
+}
+
+// Inference over SEVERAL FILES in one launch sequence (test_pointnet_att_segmen.py:127-181 runs one file per step, batch 1): file f owns the W
+// window slots f * W .. f * W + W - 1, of which its real clusters come first; the unused slots are windows of ZERO rows
+// (win_off repeats) whose key_pad_mask entry is 1, so the attention of a file sees exactly its own clusters.  Files have different point
+// counts, hence logits [n_classes, total_rows] and preds [total_rows] are over the concatenated rows (row order = file, cluster, point).
+extern "C" int ampnet_head_fwd_files_f32(const float *const *params_host, float *const *buffers_host, const float *gl, const float *lo,
+                                         const float *centroids, const int32_t *win_off, const uint8_t *key_pad_mask, int n_files, int W,
+                                         int total_rows, int max_rows, int n_classes, float *logits, long long *preds, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    AMPNET_REQUIRE(key_pad_mask, "ampnet_head_fwd_files_f32: the slot mask is required");
+    return head_fwd_impl(params_host, buffers_host, gl, lo, centroids, win_off, key_pad_mask, n_files, W, total_rows, max_rows, n_classes, 0, 0.f, 0,
+                         logits, nullptr, nullptr, preds, nullptr, workspace, workspace_bytes, stream, 1);
 }

@@ -411,6 +411,7 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
                    "ampnet_head_bwd_f32: null pointer");
     AMPNET_REQUIRE(B >= 1 && W >= 1 && W <= HEAD_MAX_W && total_rows % B == 0, "ampnet_head_bwd_f32: bad sizes");
     AMPNET_REQUIRE(n_classes >= 1 && n_classes <= HEAD_MAX_CLASSES, "ampnet_head_bwd_f32: n_classes=%d", n_classes);
+    TRY(ws_tag_check(fwd_workspace, "ampnet_head_bwd_f32"));
     hipStream_t st = (hipStream_t)stream;
     const HeadShape s = head_shape(B, W, total_rows, max_rows, n_classes, 1);
     HeadWs f;

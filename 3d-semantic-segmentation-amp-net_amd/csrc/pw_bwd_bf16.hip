@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 tr_operand(const __bf16 *tile, int ld, int row
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * ld));
     // whole-vector bit casts + one shuffle: an element-by-element short -> __bf16 copy is miscompiled by this hipcc (ROCm 7.2: it keeps
-    // only the first dword of each read; scratch/tr_probe.hip checks the operand map on the hardware)
+    // only the first dword of each read; tools/tr_probe.hip checks the operand map on the hardware)
     return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 

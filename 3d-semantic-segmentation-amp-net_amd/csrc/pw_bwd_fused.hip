@@ -201,7 +201,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     // waves 0, 1 own the three tiles over two column blocks {B0, B1} = {0, 1} / {2, 3}: (B0,B0) (B0,B1) (B1,B1); waves 2, 3 own
     // (0,B2) (1,B2) with B2 = 2 / 3.  Operand A of a tile and operand B of another are the same LDS words (same lane mapping), so a
     // wave reads each of its 2 or 3 column blocks ONCE per k step: 10 LDS reads per 10 MFMAs instead of 20 (an LDS read costs
-    // issue cycles the matrix pipe does not get back, scratch/mfma_probe2.hip)
+    // issue cycles the matrix pipe does not get back, tools/mfma_probe2.hip)
     const int sym_b0 = ww == 1 ? 2 : 0, sym_b1 = ww == 1 ? 3 : 1, sym_b2 = ww == 3 ? 3 : 2;
     const bool sym3 = ww < 2;
     float wys[TYW], wyt[TYW];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                     addv[e] = rr < valid ? a.add[(size_t)(trow0 + rr) * CY + dcol] : 0.f;
                 }
             }
-            // one accumulator, started at the per-slot bias: dependent fp32 MFMAs issue back to back at full rate (scratch/mfma_probe2.hip),
+            // one accumulator, started at the per-slot bias: dependent fp32 MFMAs issue back to back at full rate (tools/mfma_probe2.hip),
             // and every add saved in the epilogue is matrix-pipe time (VALU does not overlap with fp32 MFMA here)
             f32x16 acc0;
 #pragma unroll

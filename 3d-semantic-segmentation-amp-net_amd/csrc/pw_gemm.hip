@@ -65,7 +65,7 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // ABF / ZBF (BF kernels only): A / Z are bf16 tensors (activation storage of precision mode 3); compile-time so that the K loop
 // stays one basic block (as a run-time flag the bf16 kernels ran 10-35 % slower).
 // PIPE (fp32 path, the default; AMPNET_PW_PIPE=0 turns it off): the operands of a k step are read / computed one step ahead under the MFMAs of the
-// current step (scratch/ab_pw_pipe.py compares the two forms on one box in one process).
+// current step (tools/ab_pw_pipe.py compares the two forms on one box in one process).
 template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     // MaxPool: BatchNorm + ReLU are monotone per channel with the direction of sign(gamma) (scale = gamma * invstd), so one
     // signed extreme per channel is enough: ext = max over rows of sgn * v (the sign is folded into the staged weights).
     // The accumulators start at bias - z0, so a finished tile holds d = z - z0 directly (no bias add, no subtraction per element:
-    // VALU instructions do not overlap with fp32 MFMAs on this part -- scratch/mfma_probe.hip -- so every epilogue instruction is
+    // VALU instructions do not overlap with fp32 MFMAs on this part -- tools/mfma_probe.hip -- so every epilogue instruction is
     // time taken from the matrix pipe).  z0 is only known after the wave's first tile of the block of rows: that tile starts at
     // bias and has z0 subtracted once it is known.
     f32x2 s_sum2[NT], s_sq2[NT];
@@ -579,7 +579,7 @@ static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
     if (matrix_precision() == AMPNET_PRECISION_F32) {
         // one-step-ahead operand reads: 2.3 % on the train step, 5.9 % on the eval forward in an interleaved same-box A/B
-        // (scratch/ab_pw_pipe.py); AMPNET_PW_PIPE=0 selects the plain K loop
+        // (tools/ab_pw_pipe.py); AMPNET_PW_PIPE=0 selects the plain K loop
         const char *pe = getenv("AMPNET_PW_PIPE");
         if (pe && pe[0] == '0') return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
         return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true>(a, st);

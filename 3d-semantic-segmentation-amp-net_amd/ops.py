@@ -134,6 +134,31 @@ def head_forward(head_params, head_buffers, gl, lo, centroids, win_off, mask, B,
     return logits, preds, loss
 
 
+def head_forward_files(head_params, head_buffers, gl, lo, centroids, win_off, mask, n_files, W, total_rows, max_rows, n_classes, ws):
+    """Eval forward of the attention head for several files at once (include/ampnet_hip.h: ampnet_head_fwd_files_f32): gl [n_files*W, 256],
+    lo [total_rows, 64], centroids [n_files, W, 2], win_off [n_files*W + 1] (unused slots = zero-row windows), mask [n_files, W] uint8
+    -> (logits [n_classes, total_rows], preds [total_rows] int64)."""
+    for t, name in ((gl, "gl"), (lo, "lo"), (centroids, "centroids"), (mask, "mask")):
+        _lib.require_gpu(t, name)
+    if tuple(gl.shape) != (n_files * W, P.GLOBAL_DIM) or tuple(lo.shape) != (total_rows, P.LOCAL_DIM) or tuple(centroids.shape) != (n_files, W, 2) \
+            or tuple(mask.shape) != (n_files, W) or mask.dtype != torch.uint8 or win_off.numel() != n_files * W + 1:
+        raise _lib.AmpnetError(f"head_forward_files: shapes gl {tuple(gl.shape)} lo {tuple(lo.shape)} centroids {tuple(centroids.shape)} "
+                               f"mask {tuple(mask.shape)} do not match n_files={n_files} W={W} rows={total_rows}")
+    dev = gl.device
+    L = _lib.lib()
+    L.ampnet_head_workspace_bytes.restype = ctypes.c_size_t
+    buf = ws.get(L.ampnet_head_workspace_bytes(n_files, W, total_rows, max_rows, n_classes, 0), dev)
+    logits = torch.empty((n_classes, total_rows), dtype=torch.float32, device=dev)
+    preds = torch.empty(total_rows, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.ampnet_head_fwd_files_f32(head_params.arr, head_buffers.arr, _lib.ptr(gl.contiguous().float()), _lib.ptr(lo.contiguous().float()),
+                                         _lib.ptr(centroids.contiguous().float()), _lib.ptr(win_off), _lib.ptr(mask.contiguous()), n_files, W,
+                                         total_rows, max_rows, n_classes, _lib.ptr(logits), _lib.ptr(preds), _lib.ptr(buf),
+                                         ctypes.c_size_t(buf.numel()), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_head_fwd_files_f32")
+    return logits, preds
+
+
 def gru_head_forward(head_params, head_buffers, gl, lo, win_off, B, W, total_rows, max_rows, n_classes, train, drop_p, seed, ws,
                      targets=None, class_w=None, want_preds=False):
     """SegmentationWithGRU on the HIP path: gl [B*W, 256] (row b*W+w = global_seq[b, w]), lo [total_rows, 64]

@@ -40,8 +40,50 @@ def segment_file(base_pointnet, segmen_net, clusters_list, centroids, device):
     return preds.reshape(-1).cpu(), targets.reshape(-1)
 
 
+def segment_files(base_pointnet, segmen_net, files, device):
+    """Several files per launch sequence: files = list of (clusters_list, centroids) as segment_file takes them.  All clusters of all
+    files go through the encoder as ONE ragged launch sequence and through the head as one (ampnet_head_fwd_files_f32: a file's clusters
+    occupy the first slots of its row of W_max window slots, the rest are zero-row windows masked out of its attention).  Returns a list of
+    (preds, targets) per file, identical to segment_file's file by file: eval-mode BatchNorm uses running statistics and the attention
+    is per file, so nothing a file computes depends on its neighbours (tests/test_inference_gpu.py)."""
+    from .. import ops
+    if not files:
+        return []
+    n_files = len(files)
+    sizes = [[int(c.shape[0]) for c in cl] for cl, _ in files]
+    W = max(len(s) for s in sizes)
+    targets = [torch.cat(get_labels([c.clone() for c in cl]), dim=0).reshape(-1) for cl, _ in files]
+    flat = [n for s in sizes for n in s]
+    rows = torch.cat([torch.as_tensor(c)[:, :9].float() for cl, _ in files for c in cl], dim=0).to(device)
+    cent = torch.zeros(n_files, W, 2)
+    mask = torch.ones(n_files, W, dtype=torch.uint8)
+    slot_sizes, real_slots = [], []
+    for f, (s, (_, ce)) in enumerate(zip(sizes, files)):
+        cent[f, :len(s)] = torch.as_tensor(ce).float().reshape(len(s), 2)
+        mask[f, :len(s)] = 0
+        slot_sizes += s + [0] * (W - len(s))
+        real_slots += [f * W + w for w in range(len(s))]
+    with torch.no_grad():
+        local, glob, _ = base_pointnet.forward_windows(rows, np_cluster=flat)
+        gl = torch.zeros(n_files * W, glob.shape[1], dtype=torch.float32, device=device)
+        gl[torch.tensor(real_slots, device=device)] = glob                      # real clusters into their slots (device copy)
+        off, total, mx = ops.window_offsets(slot_sizes, rows.device)
+        pt, bt = segmen_net._tables()
+        _, preds = ops.head_forward_files(pt, bt, gl, local, cent.to(device), off, mask.to(device), n_files, W, total, mx, segmen_net.num_classes,
+                                          segmen_net._ws)
+    preds = preds.cpu()
+    out, r0 = [], 0
+    for s, t in zip(sizes, targets):
+        n = sum(s)
+        out.append((preds[r0:r0 + n], t))
+        r0 += n
+    return out
+
+
 def test(dataset_path, out_path, n_points, number_of_workers, model_checkpoint, path_list_files, cluster_dir='k_means_25',
-         device='cuda', allow_pickle=None):
+         device='cuda', allow_pickle=None, files_per_launch=1):
+    """files_per_launch (not in the reference, which runs batch 1): how many files share one launch sequence (segment_files); the
+    per-file metrics, their order and the CSV row are the same for any value."""
     start = time.time()
     device = torch.device(device)
     checkpoint = torch.load(model_checkpoint, map_location=device, weights_only=True)
@@ -60,11 +102,23 @@ def test(dataset_path, out_path, n_points, number_of_workers, model_checkpoint, 
     print(f"Total Trainable Params: {total_params}")
     iou = {k: [] for k in CLASS_KEYS}
     accuracy = []
-    for pc, file_name in loader:
-        name = file_name[0].split('/')[-1].split('.')[0]
-        clusters = _load_list(os.path.join(cluster_dir, name + '_clusters_list.pkl'), allow_pickle)
-        centroids = _load_list(os.path.join(cluster_dir, name + '_centroids.pkl'), allow_pickle)
-        preds, targets = segment_file(base_pointnet, segmen_net, clusters, torch.as_tensor(centroids), device)
+    def results():
+        group = []
+        for pc, file_name in loader:
+            name = file_name[0].split('/')[-1].split('.')[0]
+            clusters = _load_list(os.path.join(cluster_dir, name + '_clusters_list.pkl'), allow_pickle)
+            centroids = _load_list(os.path.join(cluster_dir, name + '_centroids.pkl'), allow_pickle)
+            if files_per_launch <= 1:
+                yield segment_file(base_pointnet, segmen_net, clusters, torch.as_tensor(centroids), device)
+                continue
+            group.append((clusters, torch.as_tensor(centroids)))
+            if len(group) == files_per_launch:
+                yield from segment_files(base_pointnet, segmen_net, group, device)
+                group = []
+        if group:
+            yield from segment_files(base_pointnet, segmen_net, group, device)
+
+    for preds, targets in results():
         accuracy.append(get_accuracy(preds.numpy(), targets.numpy(), {}, 'segmentation')['accuracy'])
         present = set(targets.numpy().reshape(-1).tolist())
         per = [get_iou_obj(preds, targets, c) if c in present else None for c in range(5)]

@@ -94,8 +94,9 @@ def reduce_epoch_metrics(sums, ious, device=None):
     for i, v in enumerate(vals):
         ok = ~np.isnan(v)
         acc[i] = (v[ok].sum(), ok.sum())
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    from ..trainer import _collectives_on
+    dist, _, on = _collectives_on()
+    if on:
         on_gpu = dist.get_backend() == "nccl"
         t = torch.from_numpy(acc).to(device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -1,5 +1,5 @@
 """Drop-in for the reference's pointNet/model/pointnet.py (1024-d baseline PointNet, convolutions with bias):
-TransformationNet :6-44, BasePointNet :47-97, SegmentationPointNet :128-154.  Same constructor arguments, state_dict
+TransformationNet :6-44, BasePointNet :47-97, ClassificationPointNet :100-125, SegmentationPointNet :128-154.  Same constructor arguments, state_dict
 keys and SegmentationPointNet.forward contract; the eval forward runs through ampnet_pointnet_seg_fwd_f32 (variant 0).
 The reference builds these modules on the CPU and moves them with .cuda(); here `device` defaults to 'cuda'."""
 from . import _baseline as _B
@@ -27,3 +27,14 @@ class SegmentationPointNet(_B.SegHolder):
         super().__init__()
         self.base_pointnet = BasePointNet(return_local_features=True, point_dimension=point_dimension, device=device)
         self._init_head(num_classes, _G, 512, 256, 128, device)
+
+
+class ClassificationPointNet(_B.ClsHolder):
+    """pointnet.py:100-125: global feature -> fc 1024 -> 512 -> 256 (BatchNorm + ReLU) -> Dropout -> log_softmax(fc 256 -> num_classes)."""
+    VARIANT = 0
+
+    def __init__(self, num_classes, dropout=0.3, point_dimension=3, dataset='', device='cuda'):
+        super().__init__()
+        self.dataset = dataset
+        self.base_pointnet = BasePointNet(return_local_features=False, point_dimension=point_dimension, dataset=dataset, device=device)
+        self._init_head(num_classes, dropout, _G, 512, 256, True, device)

@@ -105,6 +105,16 @@ def _dist_world():
     return None, 1
 
 
+def _collectives_on():
+    """(dist, world, on): `on` = the data-parallel exchanges are to be issued -- world > 1, or a one-rank group under
+    AMPNET_FORCE_COLLECTIVES=1 (tests/test_rccl_gpu.py: the whole exchange path, async head all-reduce, work.wait(), the sync-BatchNorm
+    callback and its stream check, then runs on RCCL with one rank, where every collective is the identity and the step must equal the
+    plain single-process step)."""
+    import os
+    dist, world = _dist_world()
+    return dist, world, dist is not None and (world > 1 or os.environ.get("AMPNET_FORCE_COLLECTIVES") == "1")
+
+
 _SYNC = {"on": False}
 
 
@@ -114,8 +124,8 @@ def enable_sync_batchnorm():
     over the global batch, so that a step of N ranks equals the single-process step on the concatenated batch.  The exchanges are
     torch.distributed collectives (RCCL under the nccl backend) on views of a scratch tensor this function keeps alive.
     Call after init_process_group, with the rank's device current.  Returns True when it took effect (world size > 1)."""
-    dist, world = _dist_world()
-    if world <= 1:
+    dist, world, on = _collectives_on()
+    if not on:
         return False
     L = _lib.lib()
     L.ampnet_collective_scratch_bytes.restype = ctypes.c_size_t
@@ -169,9 +179,13 @@ def _global_loss(loss2, reg):
     return torch.stack([pack[0] / pack[1], pack[1] / world]), pack[2].sqrt().reshape(1), world
 
 
-def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.001):
+def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.001, overlap_allreduce=False):
     """Forward + loss + backward of one batch; gradients land in p.grad (views of the modules' flat buffers).
-    x [B, W, N, 9] f32, t [B, W, N] i64 (host or device), centroids [B, W, 2]."""
+    x [B, W, N, 9] f32, t [B, W, N] i64 (host or device), centroids [B, W, 2].
+    overlap_allreduce (data parallel, opt-in: fused_train_step sets it): the head's flat gradient buffer is complete before the encoder
+    backward starts, so its SUM all-reduce is issued there asynchronously and travels under the encoder backward; the work handle is
+    returned in out["pending"] = {data_ptr of the buffer: handle} and MUST be handed to reduce_gradients (which waits for it instead of
+    reducing that buffer again).  Callers that do their own gradient handling leave it off and get purely local gradients."""
     dev = next(pointnet.parameters()).device
     if dev.type != "cuda":
         raise _lib.AmpnetError("the AMP-Net HIP path needs the model on the GPU")
@@ -223,33 +237,36 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
         d_lo, d_gl = ops.head_backward(hpt, hg.table, local, cent, off, B, W, total, mx, att_net.num_classes, att_net.p_drop, seed,
                                        dlog, att_net._ws, att_net._bws)
     # data parallel: the head's gradient buffer is complete here -- its all-reduce travels while the encoder backward runs
-    dist, world = _dist_world()
-    if world > 1:
-        _PENDING[id(hg.flat)] = dist.all_reduce(hg.flat, op=dist.ReduceOp.SUM, async_op=True)
+    pending = {}
+    if overlap_allreduce:
+        dist, world, on = _collectives_on()
+        if on:
+            pending[hg.flat.data_ptr()] = dist.all_reduce(hg.flat, op=dist.ReduceOp.SUM, async_op=True)
     d_ft = torch.zeros_like(feat_T)
     ops.reg_loss_backward(feat_last, G, reg, reg_weight, d_ft[-B:])
     ops.encoder_backward(ept, eg.table, xr, off, Q, total, mx, W, local, feat_T, d_lo, d_gl, d_ft, pointnet._ws, pointnet._bws)
     eg.attach()
     hg.attach()
-    return dict(logits=logits, preds=preds, ce=loss2, reg=reg, targets_pc=targets_pc, B=B, grad_bufs=(eg.flat, hg.flat))
+    return dict(logits=logits, preds=preds, ce=loss2, reg=reg, targets_pc=targets_pc, B=B, grad_bufs=(eg.flat, hg.flat), pending=pending)
 
 
-_PENDING = {}        # id(flat gradient buffer) -> work handle of an all-reduce forward_backward already started
-
-
-def reduce_gradients(grad_bufs, optimizers):
+def reduce_gradients(grad_bufs, optimizers, pending=None):
     """Data-parallel gradient exchange: ONE all-reduce (SUM) per network over its flat gradient buffer (4.8 MB in all,
     latency-bound on xGMI), the 1 / world_size average folded into FusedAdam's kernel (or applied to p.grad for other
-    optimisers).  An all-reduce forward_backward already started for a buffer (the head's, overlapped with the encoder backward) is
-    waited for here instead of being issued again.  No-op when torch.distributed is not initialised.  Returns the world size."""
-    dist, world = _dist_world()
-    if world > 1:
+    optimisers).  `pending` = forward_backward's out["pending"]: an all-reduce already started for a buffer (the head's, overlapped with
+    the encoder backward) is waited for here instead of being issued again.  No-op when torch.distributed is not initialised.
+    Returns the world size."""
+    dist, world, on = _collectives_on()
+    if on:
+        pending = dict(pending or {})
         for flat in grad_bufs:
-            work = _PENDING.pop(id(flat), None)
+            work = pending.pop(flat.data_ptr(), None)
             if work is not None:
                 work.wait()
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        for work in pending.values():                 # handles of buffers not listed: never leave a collective un-waited
+            work.wait()
         for opt in optimizers:
             if isinstance(opt, FusedAdam):
                 opt.grad_scale = 1.0 / world
@@ -271,8 +288,8 @@ def shard_indices(n_samples, rank, world, drop_last=True):
 
 
 def fused_train_step(pointnet, att_net, optimizer_pointnet, optimizer_att, x, t, centroids, class_w):
-    out = forward_backward(pointnet, att_net, x, t, centroids, class_w)
-    reduce_gradients(out["grad_bufs"], (optimizer_pointnet, optimizer_att))
+    out = forward_backward(pointnet, att_net, x, t, centroids, class_w, overlap_allreduce=True)
+    reduce_gradients(out["grad_bufs"], (optimizer_pointnet, optimizer_att), out["pending"])
     optimizer_pointnet.step()
     optimizer_att.step()
     return out

@@ -42,6 +42,58 @@ def fps_indices(xyz, n_samples):
     return idx[0] if single else idx
 
 
+def fps_indices_ragged(rows, sizes, n_samples):
+    """FPS of MANY clouds of unequal size in one launch per size class (include/ampnet_hip.h: ampnet_fps_ragged_f32): `rows` [total, D>=3]
+    float32 GPU tensor = the clouds back to back, `sizes` their point counts, `n_samples` one int (clamped per cloud to its size) or a
+    list.  Returns a list of int32 GPU tensors (indices relative to each cloud, selection order).  Clouds are bucketed by the kernel
+    variant their size selects, so a small cloud never runs the 16384-point variant because a large one shares the call."""
+    _lib.require_gpu(rows, "rows")
+    if rows.dim() != 2 or rows.shape[1] < 3:
+        raise _lib.AmpnetError(f"fps_indices_ragged: expected rows [total, D>=3], got {tuple(rows.shape)}")
+    sizes = [int(n) for n in sizes]
+    if not sizes or min(sizes) < 1 or sum(sizes) != rows.shape[0]:
+        raise _lib.AmpnetError(f"fps_indices_ragged: sizes (sum {sum(sizes)}) do not tile the {rows.shape[0]} rows")
+    want = [int(n_samples)] * len(sizes) if np.isscalar(n_samples) else [int(v) for v in n_samples]
+    if len(want) != len(sizes) or min(want) < 1:
+        raise _lib.AmpnetError("fps_indices_ragged: n_samples must be >= 1, one per cloud")
+    want = [min(w, n) for w, n in zip(want, sizes)]
+    x = rows if rows.dtype == torch.float32 else rows.float()
+    x = x.contiguous()
+    dev, D = x.device, x.shape[1]
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    edges = (256, 1024, 2048, 4096, 8192, 16384)                         # the size classes of csrc/fps.hip: fps_dispatch
+    klass = [int(np.searchsorted(edges, n)) for n in sizes]
+    out = [None] * len(sizes)
+    L = _lib.lib()
+    L.ampnet_fps_ragged_workspace_bytes.restype = ctypes.c_size_t
+    for k in sorted(set(klass)):
+        members = [i for i, c in enumerate(klass) if c == k]
+        # the bucket's clouds as (offset, size) pairs of the SAME rows array: no copy; offsets need not be contiguous
+        coff = np.empty(len(members) + 1, dtype=np.int32)
+        ooff = np.zeros(len(members) + 1, dtype=np.int32)
+        contiguous = all(starts[members[j]] + sizes[members[j]] == starts[members[j + 1]] for j in range(len(members) - 1))
+        if contiguous:
+            base = int(starts[members[0]])
+            coff[:] = [int(starts[i]) - base for i in members] + [int(starts[members[-1]] + sizes[members[-1]]) - base]
+            xs = x[base:base + int(coff[-1])]
+        else:                                                           # interleaved classes: pack the bucket's rows once
+            xs = torch.cat([x[int(starts[i]):int(starts[i]) + sizes[i]] for i in members])
+            coff[:] = np.concatenate([[0], np.cumsum([sizes[i] for i in members])])
+        ooff[1:] = np.cumsum([want[i] for i in members])
+        max_n, total = max(sizes[i] for i in members), int(coff[-1])
+        idx = torch.empty(int(ooff[-1]), dtype=torch.int32, device=dev)
+        offs = torch.from_numpy(np.stack([coff, ooff])).to(dev)
+        need = L.ampnet_fps_ragged_workspace_bytes(total, max_n)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
+        with torch.cuda.device(dev):
+            rc = L.ampnet_fps_ragged_f32(_lib.ptr(xs), D, _lib.ptr(offs[0]), _lib.ptr(offs[1]), len(members), total, max_n, _lib.ptr(idx),
+                                         _lib.ptr(ws), ctypes.c_size_t(need), _lib.stream_ptr(dev))
+        _lib.check(rc, "ampnet_fps_ragged_f32")
+        for j, i in enumerate(members):
+            out[i] = idx[int(ooff[j]):int(ooff[j + 1])]
+    return out
+
+
 def knn_indices(xyz, centres, k):
     """Exact k-NN grouping on the GPU (BUILD-DEFINED: the reference has no k-NN, include/ampnet_hip.h: ampnet_knn_f32).
     xyz [B, N, D>=3] float32 GPU, centres [B, S] int32 point indices (e.g. fps_indices) -> int32 [B, S, k]: per centre the k
@@ -222,11 +274,6 @@ def shuffle_clusters(data, labels):
 
 
 # ---- checkpoints (utils/utils.py:422-438): same dict keys, same file naming -------------------------
-def get_cluster_centroid(pc):
-    """pc [n, >=2] tensor -> tensor [2] = (mean x, mean y)   (utils/utils.py:538-543)."""
-    return torch.stack([pc[:, 0].mean(0), pc[:, 1].mean(0)], dim=0)
-
-
 def get_labels(cluster_lists):
     """list of clusters [n_i, >=10] (column 9 = ASPRS class code) -> list of LongTensor [n_i] with the segmentation
     labels 0 background, 1 tower, 2 lines, 3 low/medium vegetation, 4 high vegetation (utils/utils.py:546-579)."""

@@ -238,6 +238,71 @@ def fps_leg(dev, B, steps, warmup, seed, cpu_baseline_s=0.0):
     return out
 
 
+def fps_many_leg(dev, steps, seed):
+    """FPS where its throughput is (the data_proc/sample_fps.py cascade over many files, package data_proc/sample_fps.py): a chip-filling
+    batch for each stage and one streaming case.  Same 16 B per (candidate, round) accounting as fps_leg."""
+    synth, U = sub("synthetic"), sub("utils.utils")
+    out = {}
+    for tag, B, N, S in (("stage2_256x8192_to_4096", 256, 8192, 4096), ("stage1_16x16384_to_8192", 16, 16384, 8192),
+                         ("stage1_256x16384_to_8192", 256, 16384, 8192), ("stream_8x32768_to_8192", 8, 32768, 8192)):
+        xyz = torch.from_numpy(synth.clouds(seed, B, N)).to(dev)
+        U.fps_indices(xyz, S)
+        torch.cuda.synchronize(dev)
+        n = max(1, min(steps, 3))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(n):
+            U.fps_indices(xyz, S)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / n
+        kern = "fps_stream_kernel" if N > 16384 else "fps_kernel"
+        out[tag] = {"clouds": B, "points": N, "samples": S, "ms": round(ms, 3), "selections_per_s": round(B * S / (ms * 1e-3), 1),
+                    "us_per_round": round(ms * 1e3 / (S - 1), 4), "achieved_GBps_algorithmic": round(float(B) * S * N * 16 / (ms * 1e-3) / 1e9, 1),
+                    "kernel": kern, "traffic": pmc_traffic_for(f"{kern}:{tag}", B * N)}
+        del xyz
+    return out
+
+
+def inference_leg(enc, att, dev, steps):
+    """The inference path the reference runs (test_pointnet_att_segmen.py:127-181): batch 1, one file of 18 ragged clusters (>= 2048 points
+    each, unequal) per step -- amp_test.segment_file, host side included (cluster concatenation, upload, prediction download: what a call
+    costs) -- and its several-files-per-launch form (amp_test.segment_files; per-file predictions identical, tests/test_inference_gpu.py)."""
+    synth, A = sub("synthetic"), sub("pointNet.amp_test")
+    was = enc.training, att.training
+    enc.eval(); att.eval()
+    files = [synth.test_file_clusters(6000 + 50 * i, 18) for i in range(16)]
+    L = sub("_lib").lib()
+    out = {"workload": "synthetic test files of 18 ragged clusters (2048 .. 2447 points each), eval forward + argmax, fp32"}
+    try:
+        for tag, group in (("batch1", 1), ("files_per_launch_4", 4), ("files_per_launch_16", 16)):
+            def run():
+                if group == 1:
+                    for cl, ce in files:
+                        A.segment_file(enc, att, cl, ce, dev)
+                else:
+                    for g0 in range(0, len(files), group):
+                        A.segment_files(enc, att, files[g0:g0 + group], dev)
+            run()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(max(1, min(steps, 3))):
+                run()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / max(1, min(steps, 3)) / len(files)
+            pts = sum(int(c.shape[0]) for cl, _ in files for c in cl) / len(files)
+            # launches per file: every ampnet kernel is counted by the event profiler's table when it is on (one pass, untimed)
+            L.ampnet_profile_enable(1)
+            run()
+            rows = profile_read()
+            L.ampnet_profile_enable(0)
+            out[tag] = {"ms_per_file": round(dt * 1e3, 4), "points_per_s": round(pts / dt, 1), "points_per_file": round(pts, 1),
+                        "instrumented_launches_per_file": round(sum(r["calls"] for r in rows) / len(files), 1)}
+    finally:
+        enc.train(was[0]); att.train(was[1])
+    return out
+
+
 def bench_fps(args, dev, rank, world, dist):
     """--mode fps: BASELINE.json configs[4] as the headline line.  Clouds are independent: replicas only, no collective."""
     B, S = args.batch or 16, 4096
@@ -316,6 +381,35 @@ def train_loop_inclusive(enc, att, trainer_mod, B, dev, steps):
         dt = (time.perf_counter() - t0) / steps
     out["device_metrics"] = {"ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N_WIN * N_POINTS / dt, 1),
                              "accuracy_last_step": round(G.metrics_from_confusion(host[-1].numpy(), 5)[0], 4)}
+    return out
+
+
+def self_check(mode, B, args, rank, world, losses, n_warm, first_terms):
+    """Loss terms of the run against tests/golden/bench_pin.json (see main()); returns the `check` object of the JSON line or exits."""
+    host = torch.stack(losses).double().cpu().numpy() if losses else np.zeros((0, 2))
+    timed = host[n_warm:]
+    if timed.size and not np.isfinite(timed).all():
+        print(f"bench.py: non-finite loss in the timed region (rank {rank}): {timed.tolist()}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    out = {"timed_losses_finite": True, "pinned": None}
+    if mode == "train" and len(host):
+        out["first_step"] = {"ce": float(host[0][0]), "reg": float(host[0][1])}
+        out["last_timed_step"] = {"ce": float(host[-1][0]), "reg": float(host[-1][1])}
+    pin_file = os.path.join(ROOT, "tests", "golden", "bench_pin.json")
+    key = {"train": "train_B64", "fwd": "fwd_B32"}[mode]
+    want_B = {"train": 64, "fwd": 32}[mode]
+    # the pin is rank 0's batch on fresh modules in fp32 with per-rank BatchNorm statistics
+    if rank == 0 and B == want_B and args.precision == "fp32" and not (world > 1 and args.sync_bn) and os.path.exists(pin_file):
+        pin = json.load(open(pin_file))
+        tol = float(pin.get("rel_tol", 1e-4))
+        got = {"ce": float(first_terms[0][0].item())} if mode == "fwd" else dict(out["first_step"])
+        bad = {k: (got[k], pin[key][k]) for k in got if k in pin[key] and not abs(got[k] - pin[key][k]) <= tol * abs(pin[key][k])}
+        if bad:
+            print(f"bench.py: first-step loss terms differ from the oracle's pin (tests/golden/bench_pin.json, rel tol {tol}): {bad}",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(4)
+        out["pinned"] = {"against": "tests/golden/bench_pin.json (oracle float32, same inputs)", "rel_tol": tol,
+                         "rel_err": {k: abs(got[k] - pin[key][k]) / abs(pin[key][k]) for k in got if k in pin[key]}}
     return out
 
 
@@ -440,14 +534,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # Self-check (never inside the timed region's clock: device tensors are kept, read after the final synchronisation):
+    #  * the FIRST step of the fresh modules must reproduce the oracle's loss terms on the same inputs (tests/golden/bench_pin.json,
+    #    made by tests/golden/make_bench_pin.py and re-derived on the GPU box by tests/test_fullsize_gpu.py) within 1e-4 relative;
+    #  * every timed step's ce / reg must be finite.
+    # A failed check prints to stderr and exits non-zero WITHOUT a JSON line.
+    losses = []
+    if mode == "fwd":
+        with torch.no_grad():
+            first = S.forward_batch(enc, att, x, t, centd, cw, want_loss=True, want_preds=False)
+        first_terms = (first["ce"][:1].clone(), None)
+    else:
+        first_terms = None
+
+    def checked_step():
+        out = step()
+        if mode == "train":
+            losses.append(torch.stack([out["ce"][0], out["reg"].reshape(-1)[0]]))
+        return out
+
     for _ in range(args.warmup):
-        step()
+        checked_step()
+    n_warm = len(losses)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        checked_step()
     sync()
     dt = time.perf_counter() - t0
+    check = self_check(mode, B, args, rank, world, losses, n_warm, first_terms)
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -520,10 +635,12 @@ def main():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         ar_ms = (time.perf_counter() - t4) / args.steps * 1e3
-    incl = fps = None
+    incl = fps = infer = None
     if mode == "train" and world == 1 and not args.no_extra_legs:
         incl = train_loop_inclusive(enc, att, trainer_mod, B, dev, max(args.steps // 2, 3))
         fps = fps_leg(dev, 16, max(args.steps // 2, 3), 1, 200, 0.0 if args.no_cpu_baseline else 5.0)
+        fps["many_clouds"] = fps_many_leg(dev, args.steps, 210)
+        infer = inference_leg(enc, att, dev, args.steps)
 
     if rank == 0:
         pts_step = B * N_WIN * N_POINTS
@@ -546,7 +663,8 @@ def main():
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
-            "train_loop_inclusive": incl, "fps": fps,
+            "train_loop_inclusive": incl, "fps": fps, "inference": infer,
+            "check": check,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))

@@ -58,6 +58,16 @@ size_t ampnet_fps_workspace_bytes(int n_clouds, int n);
 int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t *idx, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* The same sampling for a RAGGED batch -- what one stage of data_proc/sample_fps.py:12-34 does to a directory of files of unequal size,
+ * in ONE launch: cloud b = rows cloud_off[b] .. cloud_off[b + 1] of rows [total_rows, ld]; its out_off[b + 1] - out_off[b] samples (clamped
+ * to the cloud's size) go to idx[out_off[b] ..) as indices RELATIVE to the cloud, selection order, first = 0.  cloud_off / out_off:
+ * DEVICE int32 arrays of n_clouds + 1 ascending offsets; max_n = the largest cloud (picks the kernel: every cloud of the launch runs the
+ * variant built for max_n, so callers bucket files by size class -- data_proc/sample_fps.py of the package does).  Same arithmetic, same
+ * tie rule, bit-identical to ampnet_fps_f32 cloud by cloud.  max_n > AMPNET_FPS_RESIDENT_MAX needs ampnet_fps_ragged_workspace_bytes().  */
+size_t ampnet_fps_ragged_workspace_bytes(int total_rows, int max_n);
+int ampnet_fps_ragged_f32(const float *rows, int ld, const int32_t *cloud_off, const int32_t *out_off, int n_clouds, int total_rows,
+                          int max_n, int32_t *idx, void *workspace, size_t workspace_bytes, void *stream);
+
 /* diagnostic build of the 8192-point kernel (one cloud): stamps[4 r + {0,1,2,3}] = s_memtime of thread 0 after the update,
  * after the barrier, after the slot fold and after the winner's coordinates landed in round r (FPS round anatomy).
  * The stamps go to a buffer nothing else reads; idx is the ordinary result.                                              */
@@ -139,6 +149,16 @@ int ampnet_encoder_bwd_f32(const float *const *params_host, float *const *grads_
  *   targets    [B, P] int64 (-1 = ignore), class_w [n_classes], preds [B, P] int64, loss_out [2]
  *              (weighted-mean CE, sum of weights): all optional (NULL).                              */
 size_t ampnet_head_workspace_bytes(int B, int W, int total_rows, int max_rows, int n_classes, int train);
+/* The eval forward for SEVERAL FILES in one launch sequence (the reference's test loop, test_pointnet_att_segmen.py:127-181, runs one file
+ * of <= W ragged clusters per step at batch 1): file f owns the window slots f * W .. f * W + W - 1, its real clusters first; unused slots
+ * are windows of zero rows (win_off repeats its value) with key_pad_mask[f, w] = 1, so a file's attention sees exactly its own clusters.
+ * Files differ in their point counts: logits [n_classes, total_rows] and preds [total_rows] run over the concatenated rows.
+ * workspace: ampnet_head_workspace_bytes(n_files, W, total_rows, max_rows, n_classes, 0).  Results are identical, file by file, to
+ * ampnet_head_fwd_f32 with B = 1 (tests/test_inference_gpu.py).                                                                   */
+int ampnet_head_fwd_files_f32(const float *const *params_host, float *const *buffers_host, const float *gl, const float *lo,
+                              const float *centroids, const int32_t *win_off, const uint8_t *key_pad_mask, int n_files, int W,
+                              int total_rows, int max_rows, int n_classes, float *logits, long long *preds, void *workspace,
+                              size_t workspace_bytes, void *stream);
 int ampnet_head_fwd_f32(const float *const *params_host, float *const *buffers_host, const float *gl,
                         const float *lo, const float *centroids, const int32_t *win_off,
                         const uint8_t *key_pad_mask, int B, int W, int total_rows, int max_rows, int n_classes,
@@ -288,8 +308,11 @@ int ampnet_set_collective(ampnet_collective_fn fn, void *ctx, int rank, int worl
 /* AMPNET_PRECISION_BF16_STORE: AMPNET_PRECISION_BF16_TRAIN, and the activations a train step keeps for its backward (the nine
  * pre-BatchNorm tensors of the encoder, z2 / z3 of the head) are STORED as bf16 (rounded once from the fp32 accumulator; the
  * BatchNorm statistics are taken before the rounding): the step moves about a third fewer HBM bytes.  Inputs, outputs (local,
- * global, feat_T, logits), gradients and parameters stay fp32.  The forward workspace of this mode can only be read by a
- * backward call made in the same mode.                                                                                        */
+ * global, feat_T, logits), gradients and parameters stay fp32.
+ * ENFORCED: every train-mode ampnet_encoder_fwd_f32 / ampnet_head_fwd_f32 / ampnet_gru_head_fwd_f32 records (on the host) the mode its
+ * workspace was written in; the matching *_bwd_f32 returns AMPNET_E_ARG when the storage format differs (mode 3 on one side only), or on a
+ * workspace that holds no train-mode forward of this process, instead of misreading the saved activations (tests/test_bf16_gpu.py).
+ * Modes 0 .. 2 share the fp32 tape: a backward in one of them may follow a forward in another.                                   */
 #define AMPNET_PRECISION_BF16_STORE 3
 int ampnet_set_matrix_precision(int mode);
 int ampnet_get_matrix_precision(void);
@@ -325,6 +348,28 @@ int ampnet_pointnet_seg_train_fwd_f32(const float *const *layers_host, int varia
 int ampnet_pointnet_seg_bwd_f32(const float *const *layers_host, float *const *grads_host, int variant, const float *x, int B, int N,
                                 int n_classes, const float *dlogits, const float *d_feat_T, void *workspace, size_t workspace_bytes,
                                 void *stream);
+
+/* ---- f4: the baseline classification PointNet (train and eval) ---------------------------------------------------------------
+ * replaces ClassificationPointNet.forward of pointNet/model/pointnet.py:100-125 (variant 0: fc 1024 -> 512 -> 256 -> n_classes with bias)
+ * and of pointNet/model/light_pointnet_256.py:100-125 (variant 1: fc 256 -> 128 -> 64 without bias, -> n_classes with bias), and
+ * loss.backward() through it: global feature of BasePointNet(return_local_features=False) -> relu(bn_1(fc_1)) -> relu(bn_2(fc_2)) ->
+ * Dropout(p) -> log_softmax(fc_3).  Same tape as the segmentation model (csrc/baseline_train.hip); built for parity, not tuned.
+ *   layers_host  [AMPNET_POINTNET_CLS_LAYERS * 6], per layer as above; layer order 0-16 = base_pointnet (as above), 17-19 = fc_1 (bn_1),
+ *                fc_2 (bn_2), fc_3 (none)
+ *   train != 0:  batch statistics (running statistics updated in place), dropout keep(i) = hash(seed, i) >= p * 2^32 scaled 1 / (1 - p)
+ *                (the package's counter hash, restated by oracle/ampnet_oracle.py:keep_mask -- not torch's Philox stream); B >= 2
+ *   train == 0:  running statistics, no dropout
+ *   x [B, N, 9] -> log_probs [B, n_classes]; feat_T [B, 64, 64] = feature_transform.
+ * The backward takes (d_log_probs [B, n_classes], d_feat_T [B, 64, 64] or NULL), the drop_p / seed of the forward and its untouched
+ * workspace; grads_host [AMPNET_POINTNET_CLS_LAYERS * 4] as above, every gradient overwritten.                                      */
+#define AMPNET_POINTNET_CLS_LAYERS 20
+size_t ampnet_pointnet_cls_workspace_bytes(int variant, int B, int N, int n_classes);
+int ampnet_pointnet_cls_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N, int n_classes, int train,
+                                float drop_p, uint32_t seed, float *log_probs, float *feat_T, void *workspace, size_t workspace_bytes,
+                                void *stream);
+int ampnet_pointnet_cls_bwd_f32(const float *const *layers_host, float *const *grads_host, int variant, const float *x, int B, int N,
+                                int n_classes, float drop_p, uint32_t seed, const float *d_log_probs, const float *d_feat_T,
+                                void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- a7: optimiser -----------------------------------------------------------------------------------------
  * replaces torch.optim.Adam.step as the reference configures it (train_pointnet-attention.py:140-141,469-470):

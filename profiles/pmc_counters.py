@@ -2,8 +2,8 @@
 """Per-kernel averages of rocprofv3 PMC passes (each pass its own run with --kernel-trace only, MI355X_MICROARCH.md).
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 scratch/prof_step.py 2
-  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/sq -- python3 scratch/prof_step.py 2
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 tools/prof_step.py 2
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/sq -- python3 tools/prof_step.py 2
   python profiles/pmc_counters.py $OUT profiles/r02_pmc_counters.json
 
 Output: {"<kernel symbol>|grid=<n>": {"launches": n, "<counter>": mean per launch, ..., "mfma_busy": f}}.

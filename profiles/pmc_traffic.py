@@ -4,7 +4,7 @@ prescribes) into HBM bytes per launch for the kernels bench.py names in its `roo
 
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc/FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc/WRITE_SIZE -- python3 bench.py ...
-  python profiles/pmc_traffic.py gpurun_out/pmc/train profiles/pmc_traffic.json [rows] [--fps gpurun_out/pmc/fps]   (scratch/run_pmc.sh runs the passes)
+  python profiles/pmc_traffic.py gpurun_out/pmc/train profiles/pmc_traffic.json [rows] [--fps gpurun_out/pmc/fps]   (tools/run_pmc.sh runs the passes)
 
 gfx950 corrections: FETCH_SIZE is in KiB and reports HALF of the bytes of wide coalesced reads (x 2); WRITE_SIZE in KiB
 reads exact.  A bench.py event name such as `pw_gemm<128,128>+pool` is a subset of the launches of one kernel symbol
@@ -52,7 +52,7 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None):
             name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "")
         if name and (name not in events or int(grid) > events[name]["grid"]):
             events[name] = dict(v, grid=int(grid), symbol=sym)
-    # configs[4] kernels (scratch/prof_fps.py: 16 clouds x 8192 points -> 4096 samples, k = 32): their own passes, their own workload size.
+    # configs[4] kernels (tools/prof_fps.py: 16 clouds x 8192 points -> 4096 samples, k = 32): their own passes, their own workload size.
     # Their loads are 4-byte strided, a width the FETCH_SIZE x 2 correction is not calibrated for: the raw counter is kept next to it.
     if fps_src:
         ff, fw = per_dispatch(fps_src, "FETCH_SIZE"), per_dispatch(fps_src, "WRITE_SIZE")

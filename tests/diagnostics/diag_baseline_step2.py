@@ -2,7 +2,7 @@
 (two torch.optim.Adam steps, B = 4, N = 512), and between those and the reference's golden?  CPU only."""
 import os, sys, importlib
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import baseline_state
 PK = "3d-semantic-segmentation-amp-net_amd"

@@ -1,7 +1,7 @@
 """CPU: conditioning of the BatchNorm-backward sums of the GRU head's bn_3 per channel (float64 oracle)."""
 import os, sys, importlib
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import ampnet_oracle as O
 from helpers import torch_params

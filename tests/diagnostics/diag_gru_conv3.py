@@ -1,7 +1,7 @@
 """Where does the 6e-4 error of the GRU head's conv_3.weight gradient sit?  (noise spread over the matrix, or a block of it?)"""
 import os, sys, importlib
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gru_gpu as TG
 from conftest import sub

@@ -1,8 +1,8 @@
 """Where does each gradient tensor of the step golden sit: HIP vs the reference's fp32 gradient (golden), vs the float64 oracle,
-and the reference / torch-fp32 oracle vs float64 (the noise yardsticks).  python scratch/diag_step_grads.py"""
+and the reference / torch-fp32 oracle vs float64 (the noise yardsticks).  python tests/diagnostics/diag_step_grads.py"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import sub
 from oracle import ampnet_oracle as O

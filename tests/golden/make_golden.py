@@ -334,6 +334,116 @@ def sec_baseline_train():
         save(tag, seed_base=np.array([base]), **res)
 
 
+def _baseline_train_section(tr, mk, base, Bn, N, tag):
+    """Two steps of the reference's baseline train_loop on a seeded [Bn, N, 9] batch -> fixture `tag` (see sec_baseline_train).
+    The same two steps are then repeated with torch's default dtype set to float64 (the reference's code unchanged: its
+    `torch.Tensor(pc)`, `torch.eye` and the module's parameters all follow the default dtype), and the float64 loss terms, gradient norms,
+    small gradients and running statistics are stored next to the float32 ones (suffix 64): their distance is the reference's OWN float32
+    noise, the yardstick for what any float32 implementation can be held to at the second step."""
+    res = {}
+    _baseline_two_steps(tr, mk, base, Bn, N, res, "")
+    torch.set_default_dtype(torch.float64)
+    try:
+        _baseline_two_steps(tr, mk, base, Bn, N, res, "64")
+    finally:
+        torch.set_default_dtype(torch.float32)
+    save(tag, seed_base=np.array([base]), shape=np.array([Bn, N]), **res)
+
+
+def _baseline_two_steps(tr, mk, base, Bn, N, res, sfx):
+    net = mk()
+    table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in baseline_state(synth, table, base).items()}, strict=False)
+    x = synth.windows(83, Bn, N)
+    t = synth.labels_for(x, 83)
+    t[0, :40] = -1
+    ce = torch.nn.CrossEntropyLoss(weight=torch.tensor([1., 2., 2., 1., 1.]), reduction="mean", ignore_index=-1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    full = sfx == ""
+    for step in (1, 2):
+        np.random.seed(2100 + step)
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
+        m, tpc, preds, _ = tr.train_loop(data, opt, ce, net, None, True, 0, 0)
+        res[f"s{step}_ce{sfx}"] = m["ce_loss"].detach().numpy()
+        res[f"s{step}_reg{sfx}"] = m["reg_loss"].detach().numpy()
+        res[f"s{step}_loss{sfx}"] = m["loss"].detach().numpy()
+        res[f"s{step}_preds{sfx}"] = preds.numpy().astype(np.int8)
+        for k, p in net.named_parameters():
+            g = p.grad.detach().double()
+            res[f"s{step}_gnorm{sfx}/{k}"] = np.array([g.norm().item(), g.sum().item()])
+            if p.numel() <= 2048:
+                res[f"s{step}_grad{sfx}/{k}"] = p.grad.detach().numpy()
+            if full:
+                res[f"s{step}_psum/{k}"] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                res[f"s{step}_buf{sfx}/{k}"] = v.numpy().copy()
+    np.random.seed(2109)
+    with torch.no_grad():
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
+        m, _, preds, _ = tr.train_loop(data, opt, ce, net, None, False, 0, 0)
+    res[f"eval_ce{sfx}"] = m["ce_loss"].numpy()
+    if full:
+        res["eval_preds"] = preds.numpy()
+
+
+def sec_baseline_train16():
+    """a12 at B = 16 (round-2 review: with B = 4 rows in the T-Net FC BatchNorms the second optimisation step is fp32 noise in ANY
+    implementation, so it pinned nothing): the reference's own train_loop (pointNet/baseline/train_segmentation.py:274-328) on a seeded
+    [16, 512, 9] batch, two train steps + one eval pass; every gradient norm, the small gradients in full at BOTH steps, parameter sums,
+    running statistics after each step."""
+    tr = load_script(os.path.join(REF, "pointNet/baseline/train_segmentation.py"), "ref_train_seg")
+    from pointNet.model.pointnet import SegmentationPointNet
+    from pointNet.model.light_pointnet_256 import SegmentationPointNet as LightSeg
+    _baseline_train_section(tr, lambda: SegmentationPointNet(num_classes=5, point_dimension=3), 9000, 16, 512, "baseline_train_b16")
+    _baseline_train_section(tr, lambda: LightSeg(num_classes=5, point_dimension=2, device="cpu"), 9500, 16, 512, "baseline_light_train_b16")
+
+
+def sec_baseline_cls():
+    """f4, the baseline classification modules: pointNet/model/pointnet.py:100-125 ClassificationPointNet(num_classes, dropout, point_dimension=3)
+    and pointNet/model/light_pointnet_256.py:100-125 (point_dimension=2, the only value its BasePointNet accepts, :71).  Their drivers cannot
+    run in the reference as committed, so the MODULES are pinned: eval output (log-probabilities, feature transform) on
+    [4, 512, 9]; one train-mode step's forward and autograd on [16, 512, 9] with dropout 0 -- NLL of the log-probabilities against seeded labels
+    + 0.001 * the feature-transform regulariser (the loss recipe of the baseline drivers, train_segmentation.py:300-306) -- with every
+    gradient, and the running statistics after it."""
+    from pointNet.model.pointnet import ClassificationPointNet
+    from pointNet.model.light_pointnet_256 import ClassificationPointNet as LightCls
+    n_cls = 4
+    for tag, mk, base in (("baseline_cls", lambda dp: ClassificationPointNet(n_cls, dropout=dp, point_dimension=3), 9700),
+                          ("baseline_light_cls", lambda dp: LightCls(n_cls, dropout=dp, point_dimension=2, device="cpu"), 9800)):
+        net = mk(0.3)
+        table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+        state = {k: torch.from_numpy(v) for k, v in baseline_state(synth, table, base).items()}
+        net.load_state_dict(state, strict=False)
+        net.eval()
+        res = {"names": np.array(list(table.keys())), "shapes": np.array([";".join(map(str, s)) for s in table.values()])}
+        with torch.no_grad():
+            out, ft = net(torch.from_numpy(synth.windows(84, 4, 512)))
+        res["eval_out"], res["eval_feat_T"] = out.numpy(), ft.numpy()
+        net = mk(0.0)
+        net.load_state_dict(state, strict=False)
+        net.train()
+        x = torch.from_numpy(synth.windows(85, 16, 512))
+        y = torch.from_numpy((synth.uniform(86, (16,), 0.0, 1.0) * n_cls).astype(np.int64).clip(0, n_cls - 1))
+        out, ft = net(x)
+        nll = torch.nn.functional.nll_loss(out, y)
+        reg = torch.norm(torch.eye(64) - torch.bmm(ft, ft.transpose(2, 1)))
+        (nll + 0.001 * reg).backward()
+        res.update(train_out=out.detach().numpy(), train_feat_T=ft.detach().numpy(), labels=y.numpy(), nll=np.array([nll.item()]), reg=np.array([reg.item()]))
+        for k, p in net.named_parameters():
+            g = p.grad.detach()
+            res[f"gnorm/{k}"] = np.array([g.double().norm().item(), g.double().sum().item()])
+            if g.numel() <= 16384:
+                res[f"grad/{k}"] = g.numpy()
+            else:                                   # large tensors: norm + sum above and every stride-th element (<= 4096 of them)
+                stride = -(-g.numel() // 4096)
+                res[f"gsample/{k}"] = g.reshape(-1)[::stride].numpy().copy()
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                res[f"buf/{k}"] = v.numpy().copy()
+        save(tag, seed_base=np.array([base]), **res)
+
+
 def sec_gru():
     """f4: SegmentationWithGRU (pointnetAtt.py:212-258) eval forwards (uniform and ragged windows) and the reference's GRU train_loop
     (pointNet/rnn/train_pointnetGRU.py:335-441): eval, then two train steps.  The module hard-codes nn.Dropout(0.3); its p is set to 0
@@ -434,7 +544,7 @@ def sec_cls():
     save("cls", **res)
 
 
-SECTIONS = dict(cls=sec_cls, gru=sec_gru, baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
+SECTIONS = dict(baseline_cls=sec_baseline_cls, baseline_train16=sec_baseline_train16, cls=sec_cls, gru=sec_gru, baseline_train=sec_baseline_train, fps=sec_fps, encoder=sec_encoder, head=sec_head, step=sec_step, metrics=sec_metrics,
                 collate=sec_collate, dataset=sec_dataset, baseline=sec_baseline)
 
 if __name__ == "__main__":

@@ -1,0 +1,165 @@
+"""The baseline classification PointNets (pointNet/model/pointnet.py:100-125 and light_pointnet_256.py:100-125) on the HIP
+tape of csrc/baseline_train.hip, against outputs of the reference MODULES themselves (tests/golden/baseline_cls.npz,
+baseline_light_cls.npz, made by tests/golden/make_golden.py:sec_baseline_cls; the reference's classification DRIVERS cannot run as
+committed, DESIGN.md section 7, so the modules are what is pinned).
+Bars: eval log-probabilities / feature transform 1e-4 absolute; train-mode (dropout 0, B = 16) loss terms 1e-4 relative, outputs 1e-3,
+running statistics 1e-3, every gradient within 3e-2 of its norm + 1e-5 of the total (B = 16 rows in the FC BatchNorms: the reference's
+own float32 autograd sits 1e-2 .. 2e-2 from float64 on the input T-Net's tensors; the float64 check below arbitrates at the same bar); dropout 0.3 against a float64 restatement with the same keep-mask."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from conftest import sub                           # noqa: E402
+from helpers import baseline_state                 # noqa: E402
+
+N_CLS = 4
+VARIANTS = [("baseline_cls", "pointNet.model.pointnet", 3, 9700), ("baseline_light_cls", "pointNet.model.light_pointnet_256", 2, 9800)]
+
+
+def _net(synth, modname, pdim, base, dropout, device):
+    M = sub(modname)
+    net = M.ClassificationPointNet(N_CLS, dropout=dropout, point_dimension=pdim, device=device)
+    table = {k: tuple(v.shape) for k, v in net.state_dict().items() if "num_batches" not in k}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in baseline_state(synth, table, base).items()}, strict=False)
+    return net, table
+
+
+@pytest.mark.parametrize("tag,modname,pdim,base", VARIANTS)
+def test_state_dict_keys_match_reference(golden, synth, tag, modname, pdim, base):
+    """Same keys, same shapes, same order as the reference module's state_dict (CPU: parameter holders only)."""
+    g = golden(tag)
+    net, table = _net(synth, modname, pdim, base, 0.3, "cpu")
+    assert list(table.keys()) == [str(n) for n in g["names"]]
+    assert [";".join(map(str, s)) for s in table.values()] == [str(s) for s in g["shapes"]]
+    assert int(g["seed_base"][0]) == base
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,modname,pdim,base", VARIANTS)
+def test_eval_forward_matches_reference(golden, synth, tag, modname, pdim, base):
+    g = golden(tag)
+    net, _ = _net(synth, modname, pdim, base, 0.3, "cuda")
+    net.eval()
+    with torch.no_grad():
+        out, ft = net(torch.from_numpy(synth.windows(84, 4, 512)).cuda())
+    assert out.shape == (4, N_CLS) and ft.shape == (4, 64, 64)
+    assert np.abs(out.cpu().numpy() - g["eval_out"]).max() <= 1e-4
+    assert np.abs(ft.cpu().numpy() - g["eval_feat_T"]).max() <= 1e-4 * max(1.0, np.abs(g["eval_feat_T"]).max())
+    assert np.allclose(np.exp(out.cpu().numpy()).sum(1), 1.0, atol=1e-5)                 # log-probabilities
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,modname,pdim,base", VARIANTS)
+def test_train_step_matches_reference_autograd(golden, synth, tag, modname, pdim, base):
+    """One train-mode forward + backward (dropout 0) on [16, 512, 9]: NLL + 0.001 * regulariser, every gradient of the reference's autograd."""
+    g = golden(tag)
+    net, _ = _net(synth, modname, pdim, base, 0.0, "cuda")
+    net.train()
+    x = torch.from_numpy(synth.windows(85, 16, 512)).cuda()
+    y = torch.from_numpy(g["labels"]).cuda()
+    out, ft = net(x)
+    nll = torch.nn.functional.nll_loss(out, y)
+    reg = torch.norm(torch.eye(64, device="cuda") - torch.bmm(ft, ft.transpose(2, 1)))
+    (nll + 0.001 * reg).backward()
+    assert abs(nll.item() - float(g["nll"][0])) <= 1e-4 * abs(float(g["nll"][0])), (nll.item(), float(g["nll"][0]))
+    assert abs(reg.item() - float(g["reg"][0])) <= 1e-4 * abs(float(g["reg"][0])), (reg.item(), float(g["reg"][0]))
+    assert np.abs(out.detach().cpu().numpy() - g["train_out"]).max() <= 1e-3
+    assert np.abs(ft.detach().cpu().numpy() - g["train_feat_T"]).max() <= 1e-3 * max(1.0, np.abs(g["train_feat_T"]).max())
+    sd = net.state_dict()
+    for k in sd:
+        if "running" in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 1
+    gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith("gnorm/")))
+    bad, worst = [], 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        got = p.grad.detach().cpu().double().numpy()
+        ref_norm = float(g[f"gnorm/{k}"][0])
+        tol = 3e-2 * ref_norm + 1e-5 * gtot
+        if abs(np.linalg.norm(got) - ref_norm) > tol:
+            bad.append((k, "norm", float(np.linalg.norm(got)), ref_norm))
+        if f"grad/{k}" in g.files:
+            err = np.linalg.norm(got - g[f"grad/{k}"].astype(np.float64))
+        else:                                                    # large tensors: every stride-th element, scaled to the whole tensor
+            sample = g[f"gsample/{k}"].astype(np.float64)
+            stride = -(-got.size // 4096)
+            err = np.linalg.norm(got.reshape(-1)[::stride] - sample) * np.sqrt(stride)
+        worst = max(worst, err / (ref_norm + 1e-5 * gtot))
+        if err > tol:
+            bad.append((k, "grad", float(err), ref_norm))
+    assert not bad, bad
+    print(f"{tag}: worst relative gradient error vs the reference's autograd {worst:.2e}")
+
+
+def _f64_forward(sd, x, pdim, drop_keep, drop_p):
+    """float64 restatement of ClassificationPointNet.forward in train mode (batch statistics) from torch ops; sd: state_dict in float64."""
+    def lin_bn(h, pre, lin, bn, relu=True):
+        w = sd[pre + lin + ".weight"]
+        h = h @ w.reshape(w.shape[0], -1).t()
+        if pre + lin + ".bias" in sd:
+            h = h + sd[pre + lin + ".bias"]
+        if bn:
+            mu, var = h.mean(0), h.var(0, unbiased=False)
+            h = (h - mu) / torch.sqrt(var + 1e-5) * sd[pre + bn + ".weight"] + sd[pre + bn + ".bias"]
+        return torch.relu(h) if relu else h
+
+    def tnet(h, pre, k, Bn, N):
+        h = lin_bn(lin_bn(lin_bn(h, pre, "conv_1", "bn_1"), pre, "conv_2", "bn_2"), pre, "conv_3", "bn_3")
+        p = h.reshape(Bn, N, -1).max(1).values
+        p = lin_bn(lin_bn(p, pre, "fc_1", "bn_4"), pre, "fc_2", "bn_5")
+        return lin_bn(p, pre, "fc_3", None, relu=False).reshape(Bn, k, k) + torch.eye(k, dtype=torch.float64)
+    Bn, N = x.shape[0], x.shape[1]
+    T = tnet(x[:, :, :pdim].reshape(-1, pdim), "base_pointnet.input_transform.", pdim, Bn, N)
+    h = torch.cat([torch.bmm(x[:, :, :pdim], T), x[:, :, pdim:]], 2).reshape(-1, 9)
+    h = lin_bn(lin_bn(h, "base_pointnet.", "conv_1", "bn_1"), "base_pointnet.", "conv_2", "bn_2")
+    T64 = tnet(h, "base_pointnet.feature_transform.", 64, Bn, N)
+    local = torch.bmm(h.reshape(Bn, N, 64), T64).reshape(-1, 64)
+    h = lin_bn(lin_bn(lin_bn(local, "base_pointnet.", "conv_3", "bn_3"), "base_pointnet.", "conv_4", "bn_4"), "base_pointnet.", "conv_5", "bn_5")
+    glob = h.reshape(Bn, N, -1).max(1).values
+    a = lin_bn(lin_bn(glob, "", "fc_1", "bn_1"), "", "fc_2", "bn_2")
+    if drop_keep is not None:
+        a = a * drop_keep * (1.0 / (1.0 - drop_p))
+    return torch.log_softmax(lin_bn(a, "", "fc_3", None, relu=False), dim=1), T64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,modname,pdim,base", VARIANTS)
+def test_dropout_step_matches_float64_autograd(synth, tag, modname, pdim, base):
+    """Dropout 0.3 on: the kernel's keep-mask is the package's counter hash (oracle keep_mask restates it); forward and every gradient
+    against float64 autograd of the restated graph with the same mask."""
+    from oracle import ampnet_oracle as O
+    drop_p = 0.3
+    net, _ = _net(synth, modname, pdim, base, drop_p, "cuda")
+    net.train()
+    Bn, N = 16, 256
+    x = torch.from_numpy(synth.windows(87, Bn, N)).cuda()
+    y = torch.from_numpy((synth.uniform(88, (Bn,), 0.0, 1.0) * N_CLS).astype(np.int64).clip(0, N_CLS - 1)).cuda()
+    sd64 = {k: v.detach().double().cpu().clone().requires_grad_("running" not in k and "num_batches" not in k) for k, v in net.state_dict().items()
+            if "num_batches" not in k}
+    seed = net.seed & 0xFFFFFFFF
+    out, ft = net(x)
+    loss = torch.nn.functional.nll_loss(out, y) + 0.001 * torch.norm(torch.eye(64, device="cuda") - torch.bmm(ft, ft.transpose(2, 1)))
+    loss.backward()
+    c2 = net.fc_3.weight.shape[1]
+    keep = torch.from_numpy(O.keep_mask(seed, 0, Bn * c2, drop_p)).double().reshape(Bn, c2)
+    assert 0.5 < keep.mean().item() < 0.9
+    o64, T64 = _f64_forward(sd64, x.double().cpu(), pdim, keep, drop_p)
+    l64 = torch.nn.functional.nll_loss(o64, y.cpu()) + 0.001 * torch.norm(torch.eye(64, dtype=torch.float64) - torch.bmm(T64, T64.transpose(2, 1)))
+    l64.backward()
+    assert abs(loss.item() - l64.item()) <= 1e-4 * abs(l64.item()), (loss.item(), l64.item())
+    assert (out.detach().double().cpu() - o64.detach()).abs().max().item() <= 1e-3
+    gtot = np.sqrt(sum(float(v.grad.norm()) ** 2 for v in sd64.values() if v.grad is not None))
+    worst = 0.0
+    for k, p in net.named_parameters():
+        w = sd64[k].grad
+        err = (p.grad.double().cpu().reshape(w.shape) - w).norm().item()
+        worst = max(worst, err / (w.norm().item() + 1e-5 * gtot))
+        assert err <= 3e-2 * w.norm().item() + 1e-5 * gtot, (k, err, w.norm().item())
+    print(f"{tag} with dropout: worst relative gradient error vs float64 autograd {worst:.2e}")

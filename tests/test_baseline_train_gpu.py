@@ -1,7 +1,9 @@
 """Baseline PointNet TRAINING on the HIP path (BASELINE.json config 1: batch 4, N = 512, 9 features, 5 classes)
 against what the reference's own train_loop (pointNet/baseline/train_segmentation.py:274-328) returned on the same seeded batch
 (tests/golden/baseline_train.npz, baseline_light_train.npz: made by tests/golden/make_golden.py:sec_baseline_train).
-Bars: loss terms 1e-4 (step 1) / 2e-2 (step 2, behind one Adam update at B = 4); gradient norms and the small gradients stored in full 2e-2 of
+The config-1 shape [4, 512, 9] keeps its "runs end to end, loss decreases" role with the loose step-2 bars that B = 4 allows; the
+B = 16 fixtures (test_baseline_train_loop_b16_matches_reference) carry the tight bars at both steps.
+Bars at B = 4: loss terms 1e-4 (step 1) / 2e-2 (step 2, behind one Adam update at B = 4); gradient norms and the small gradients stored in full 2e-2 of
 their norm (B = 4 rows in the T-Net FC BatchNorms: the reference's own fp32 noise, tests/test_step_gpu.py); parameter sums after Adam."""
 import os
 import sys
@@ -61,7 +63,7 @@ def test_baseline_train_loop_matches_reference(golden, synth, variant):
             got = p.grad.double()
             # step-2 gradients sit behind one Adam update (lr * sign(g) per element) and the B = 4 FC BatchNorms: float32 and float64 torch
             # evaluations of this very graph then differ by 5 ... 31 % in the encoder's gradient norms and by <= 0.6 % only in the last
-            # layers of the head (scratch/diag_baseline_step2.py) -- so step 2 pins those, step 1 pins every tensor
+            # layers of the head (tests/diagnostics/diag_baseline_step2.py) -- so step 2 pins those, step 1 pins every tensor
             if step == 1 or k in STEP2_STABLE:
                 rt = 2e-2 if step == 1 else 1e-1
                 if abs(got.norm().item() - gn[0]) > rt * gn[0] + 1e-5 * gtot:
@@ -92,7 +94,7 @@ def test_baseline_train_loop_matches_reference(golden, synth, variant):
         if "running" in k:
             # after step 2: momentum 0.1 x the step-2 batch statistics, which scatter between float32 and float64 torch on this very graph by
             # 10 ... 130 % (variances) and by up to 0.38 absolute (means of the T-Net FC BatchNorms over B = 4 rows) --
-            # scratch/diag_baseline_step2.py; the statistics after step 1 are pinned to 1e-3 above
+            # tests/diagnostics/diag_baseline_step2.py; the statistics after step 1 are pinned to 1e-3 above
             np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"final_buf/{k}"], rtol=0.15, atol=0.1, err_msg=k)
     assert int(net.bn_1.num_batches_tracked) == 2
     np.random.seed(2009)
@@ -101,6 +103,78 @@ def test_baseline_train_loop_matches_reference(golden, synth, variant):
         m, _, preds, _ = B.train_loop(data, opt, ce, net, None, False, 0, 0)
     want = float(g["eval_ce"].reshape(-1)[0])
     assert abs(m["ce_loss"].item() - want) <= 3e-2 * abs(want)    # behind two noisy Adam steps
+
+
+@pytest.mark.parametrize("variant", ["baseline_train", "baseline_light_train"])
+def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
+    """The same two optimisation steps of the reference's train_loop at B = 16 (tests/golden/baseline*_train_b16.npz,
+    make_golden.py:sec_baseline_train16), which also holds the reference's OWN float64 evaluation of the two steps (its code unchanged,
+    torch's default dtype set to float64) as the arbiter.
+
+    Step 1 (depends on the seeded weights only): loss terms 1e-4, every gradient norm and every gradient stored in full within 2e-2 of
+    its norm, running statistics 1e-3, predictions.
+    Step 2 sits behind one Adam update, which moves EVERY element by lr * sign(g): where a gradient element is smaller than its float32
+    noise the direction is noise, in any implementation.  Measured on the reference itself (float32 run vs float64 run, B = 16): loss terms
+    agree to 3.4e-4, running statistics to 5e-3, but 46 of 57 gradient tensors differ by more than 5e-3 in norm and the encoder's gradients
+    by 30 .. 60 % as vectors, predictions in 4 .. 6 % of the points.  So a flat 2e-2 bar on step-2 gradients is not a property the reference
+    has; what is pinned instead: loss terms 2e-3 and running statistics 2e-2 against the float64 run, and every gradient within
+    3 x (the reference's own float32-to-float64 distance) + 2e-2 of its norm of the float64 gradient -- a bar that is 2e-2 wherever the
+    reference is reproducible (the head's last layers) and as wide as the reference's own noise elsewhere."""
+    B = sub("pointNet.baseline_seg")
+    g = golden(variant + "_b16")
+    Bn, N = (int(v) for v in g["shape"])
+    net = _net(synth, variant)
+    x = synth.windows(83, Bn, N)
+    t = synth.labels_for(x, 83)
+    t[0, :40] = -1
+    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).cuda(), reduction="mean", ignore_index=-1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    bad, worst, tight2 = [], {1: 0.0, 2: 0.0}, 0
+    for step in (1, 2):
+        np.random.seed(2100 + step)
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
+        m, tpc, preds, _ = B.train_loop(data, opt, ce, net, None, True, 0, 0)
+        rt = 1e-4 if step == 1 else 2e-3
+        for k, key in (("ce", "ce_loss"), ("reg", "reg_loss"), ("loss", "loss")):
+            want = float(g[f"s{step}_{k}64"].reshape(-1)[0])
+            if abs(m[key].item() - want) > rt * abs(want):
+                bad.append((step, k, m[key].item(), want))
+        self_mism = float((g[f"s{step}_preds"] != g[f"s{step}_preds64"]).mean())           # the reference against itself
+        mism = float((preds.numpy() != g[f"s{step}_preds64"]).mean())
+        if mism > 2.0 * self_mism + (5e-3 if step == 1 else 1e-2):
+            bad.append((step, "preds", mism, self_mism))
+        gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith(f"s{step}_gnorm64/")))
+        for k, p in net.named_parameters():
+            n32, n64 = float(g[f"s{step}_gnorm/{k}"][0]), float(g[f"s{step}_gnorm64/{k}"][0])
+            got = p.grad.double()
+            floor = 2e-2 * n64 + 1e-5 * gtot
+            if abs(got.norm().item() - n64) > 3.0 * abs(n32 - n64) + floor:
+                bad.append((step, "gnorm", k, got.norm().item(), n64, n32))
+            key = f"s{step}_grad64/{k}"
+            if key in g.files:
+                noise = np.linalg.norm(g[f"s{step}_grad/{k}"].astype(np.float64) - g[key])
+                err = np.linalg.norm(got.cpu().numpy() - g[key])
+                worst[step] = max(worst[step], err / (n64 + 1e-5 * gtot))
+                tight2 += int(step == 2 and 3.0 * noise < floor)
+                if err > 3.0 * noise + floor:
+                    bad.append((step, "grad", k, float(err), float(noise), n64))
+        sd = net.state_dict()
+        rt_buf = 1e-3 if step == 1 else 2e-2
+        for k in sd:
+            if "running" in k:
+                ref = g[f"s{step}_buf64/{k}"]
+                d = np.abs(sd[k].cpu().numpy() - ref).max()
+                if d > rt_buf * max(1.0, np.abs(ref).max()):
+                    bad.append((step, "buf", k, float(d)))
+    assert not bad, bad[:12]
+    print(f"{variant} B=16: worst relative distance of the gradients stored in full from the reference's float64 run: step 1 {worst[1]:.2e}, "
+          f"step 2 {worst[2]:.2e}; {tight2} step-2 tensors carry the plain 2e-2 bar")
+    np.random.seed(2109)
+    with torch.no_grad():
+        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
+        m, _, preds, _ = B.train_loop(data, opt, ce, net, None, False, 0, 0)
+    want = float(g["eval_ce64"].reshape(-1)[0])
+    assert abs(m["ce_loss"].item() - want) <= 5e-3 * abs(want), (m["ce_loss"].item(), want)
 
 
 def test_baseline_gradients_match_float64_autograd(synth):

@@ -268,3 +268,46 @@ def test_bf16_store_eval_forward(synth, params):
     print(f"bf16_store eval logits: max |diff| {err:.3e} (span {span:.3g})")
     assert 0.0 < err <= 3e-2 * max(span, 1.0), (err, span)
     assert (ob["preds"] != of["preds"]).float().mean().item() < 2e-2
+
+
+def test_backward_refuses_a_tape_of_another_storage_mode(synth, params):
+    """include/ampnet_hip.h, AMPNET_PRECISION_BF16_STORE: the forward records the mode its workspace was written in and the backward
+    returns AMPNET_E_ARG (-> AmpnetError) when the storage format of the saved activations differs, instead of reinterpreting fp32
+    tensors as bf16 or the reverse (an fp32 forward followed by a bf16_store backward used to pass the size check and return garbage)."""
+    ops, L = sub("ops"), sub("_lib")
+    p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
+    b = {k: torch.from_numpy(v.copy()).cuda() for k, v in synth.make_buffers(5, params.ENC_BUFFERS).items()}
+    B, W, N = 4, 3, 256
+    Q = B * W
+    xd = torch.from_numpy(synth.windows(77, Q, N).reshape(-1, 9)).cuda()
+    off, total, mx = ops.window_offsets([N] * Q, xd.device)
+    grads = {k: torch.zeros_like(v) for k, v in p.items()}
+    pt, bt, gt = ops.PointerTable(params.ENC_PARAMS, p, "p"), ops.PointerTable(params.ENC_BUFFERS, b, "b"), ops.PointerTable(params.ENC_PARAMS, grads, "g")
+    r1, r2, r3 = torch.zeros(Q * N, 64, device="cuda"), torch.ones(Q, 256, device="cuda"), torch.zeros(Q, 64, 64, device="cuda")
+    try:
+        for fwd_mode, bwd_mode in (("fp32", "bf16_store"), ("bf16_store", "fp32"), ("bf16_store", "bf16_train")):
+            fws, bws = ops.Workspace(), ops.Workspace()
+            L.set_matrix_precision(fwd_mode)
+            local, glob, ft, _ = ops.encoder_forward(pt, bt, xd, off, Q, total, mx, W, True, fws)
+            L.set_matrix_precision(bwd_mode)
+            with pytest.raises(L.AmpnetError, match="precision mode"):
+                ops.encoder_backward(pt, gt, xd, off, Q, total, mx, W, local, ft, r1, r2, r3, fws, bws)
+        # a workspace that never saw a train-mode forward
+        L.set_matrix_precision("fp32")
+        fws, bws = ops.Workspace(), ops.Workspace()
+        need = L.lib().ampnet_encoder_workspace_bytes
+        need.restype = __import__("ctypes").c_size_t
+        # (a view 256 bytes into a larger block: torch's allocator hands out 512-byte aligned blocks, so this address can never have been
+        #  the base of an earlier, since freed, workspace whose tag would still be on record)
+        fws.buf = torch.empty(int(need(Q, W, total, mx, 1)) + 256, dtype=torch.uint8, device=xd.device)[256:]
+        with pytest.raises(L.AmpnetError, match="no train-mode forward"):
+            ops.encoder_backward(pt, gt, xd, off, Q, total, mx, W, torch.zeros(Q * N, 64, device="cuda"), r3, r1, r2, r3, fws, bws)
+        # same storage format, other operand precision: allowed
+        fws, bws = ops.Workspace(), ops.Workspace()
+        local, glob, ft, _ = ops.encoder_forward(pt, bt, xd, off, Q, total, mx, W, True, fws)
+        L.set_matrix_precision("bf16_train")
+        ops.encoder_backward(pt, gt, xd, off, Q, total, mx, W, local, ft, r1, r2, r3, fws, bws)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(g).all() for g in grads.values())
+    finally:
+        L.set_matrix_precision("fp32")

@@ -169,3 +169,79 @@ def test_config3_shape_train_step_matches_oracle(synth, params):
             assert d <= 2e-4 * max(1.0, v.abs().max().item()), (k, d)
     worst, floor = _check_grads(got, want[torch.float64], want[torch.float32], "config-3-shaped step")
     print(f"full-size train step: worst relative gradient error {worst:.2e} (torch fp32 noise floor {floor:.2e})")
+
+
+def _bench_pin_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_bench_pin", os.path.join(ROOT, "tests", "golden", "make_bench_pin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_shape_train_forward_matches_oracle(synth, params):
+    """The step bench.py TIMES, verbatim (BASELINE.json configs[2]: B = 64 samples x 9 windows x 2048 points, dropout 0.3, rank-0
+    batch seed 100, fresh modules): 2304 blocks of rows, so every persistent pw_gemm workgroup runs its train-mode statistics /
+    max-pool epilogue ~9 times with slot changes in between.  trainer.forward_backward's loss terms, logits and the per-slot running
+    statistics against the oracle's float32 train-mode forward with the same dropout keep-masks (no autograd: affordable at B = 64),
+    and the oracle's numbers against tests/golden/bench_pin.json, which bench.py checks its first step against.
+    Bars: ce / reg 1e-4 relative, logits 1e-3 absolute (north_star), running statistics 2e-4 of their scale, pin file 2e-5 relative
+    (the oracle is torch-CPU float32: its summation order depends on the host's thread count)."""
+    import json
+    T = sub("trainer")
+    pin_mod = _bench_pin_module()
+    B = 64
+    enc, att = _models(synth, params, dropout=pin_mod.DROP_P)
+    assert att.seed == pin_mod.ATT_SEED and att._step == 0
+    enc.train(); att.train()
+    pc, tg, cent, _ = synth.sample_batch(100, B, N_POINTS, max_w=N_WIN)
+    x, t, centd = _device_batch(pc, tg, cent)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device="cuda")
+    out = T.forward_backward(enc, att, x, t, centd, cw)
+    torch.cuda.synchronize()
+    got_ce, got_reg, got_logits = out["ce"][0].item(), out["reg"].item(), out["logits"].cpu()
+    assert all(torch.isfinite(p.grad).all() for m in (enc, att) for p in m.parameters())
+    want = pin_mod.train_forward(synth, params, B, pin_mod.ATT_SEED)
+    assert abs(got_ce - want["ce"]) <= 1e-4 * abs(want["ce"]), (got_ce, want["ce"])
+    assert abs(got_reg - want["reg"]) <= 1e-4 * abs(want["reg"]), (got_reg, want["reg"])
+    err = (got_logits - want["logits"]).abs().max().item()
+    assert err <= 1e-3, f"B = 64 train logits: max |diff| {err:.3e}"
+    for mod, bufs in ((enc, want["eb"]), (att, want["hb"])):
+        sd = mod.state_dict()
+        for k, v in bufs.items():
+            d = (sd[k].cpu() - v).abs().max().item()
+            assert d <= 2e-4 * max(1.0, v.abs().max().item()), (k, d)
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_pin.json")))["train_B64"]
+    assert abs(want["ce"] - pin["ce"]) <= 2e-5 * abs(pin["ce"]), ("bench_pin.json is stale: rerun tests/golden/make_bench_pin.py", want["ce"], pin["ce"])
+    assert abs(want["reg"] - pin["reg"]) <= 2e-5 * abs(pin["reg"]), (want["reg"], pin["reg"])
+    print(f"bench shape: ce {got_ce:.7f} vs oracle {want['ce']:.7f}, reg {got_reg:.5f} vs {want['reg']:.5f}, logits max diff {err:.2e}")
+
+
+def test_train_step_is_bitwise_reproducible(synth, params):
+    """No float atomics, every reduction in a fixed order ("Determinism"): two fresh model pairs stepped on the
+    same batch give bit-identical losses, logits, gradients and parameters after Adam -- at a shape where the persistent kernels
+    iterate and the last-arriver finalisations run (B = 16: 576 blocks of rows)."""
+    T = sub("trainer")
+    B = 16
+    pc, tg, cent, _ = synth.sample_batch(103, B, N_POINTS, max_w=N_WIN)
+    x, t, centd = _device_batch(pc, tg, cent)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device="cuda")
+    runs = []
+    for _ in range(2):
+        enc, att = _models(synth, params, dropout=0.3)
+        tr = T.Trainer(enc, att, lr=1e-3, class_w=cw)
+        rec = []
+        for _s in range(2):
+            out = tr.step(x, t, centd)
+            rec.append((out["ce"].clone(), out["reg"].clone(), out["logits"].clone(), [p.grad.clone() for m in (enc, att) for p in m.parameters()]))
+        torch.cuda.synchronize()
+        rec.append([p.detach().clone() for m in (enc, att) for p in m.parameters()] + [b.clone() for m in (enc, att) for b in m.buffers()])
+        runs.append(rec)
+    a, b = runs
+    for s in range(2):
+        assert torch.equal(a[s][0], b[s][0]) and torch.equal(a[s][1], b[s][1]), f"step {s}: loss terms differ between two runs"
+        assert torch.equal(a[s][2], b[s][2]), f"step {s}: logits differ"
+        for i, (ga, gb) in enumerate(zip(a[s][3], b[s][3])):
+            assert torch.equal(ga, gb), f"step {s}: gradient tensor {i} differs between two runs"
+    for i, (pa, pb) in enumerate(zip(a[2], b[2])):
+        assert torch.equal(pa, pb), f"parameter / buffer {i} differs after two steps"

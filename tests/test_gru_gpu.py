@@ -155,7 +155,7 @@ def test_gru_train_loop_first_step_matches_reference(golden, synth, params):
                 ref = torch.from_numpy(g[key].astype(np.float64)).reshape(w.shape)
                 noise = max(noise, float((ref - w).norm()))
             # one activation 5e-6 from the ReLU kink of bn_3 (channel 15) moves conv_3.weight's gradient by 6e-4 when it switches side
-            # (scratch/diag_gru_conv3.py, diag_gru_bnsum.py): the allowance is what the float64 oracle itself says such switches cost
+            # (tests/diagnostics/diag_gru_conv3.py, diag_gru_bnsum.py): the allowance is what the float64 oracle itself says such switches cost
             if err > 3.0 * noise + 2e-4 * nrm + 1e-5 * gtot + 1.5 * kink[(tag, k)]:
                 bad.append(("f64", tag, k, err / (nrm + 1e-30), noise / (nrm + 1e-30), kink[(tag, k)] / (nrm + 1e-30)))
             worst = max(worst, err / (nrm + 1e-5 * gtot))

@@ -39,7 +39,7 @@ TIGHT = {("att", "conv_3.weight"), ("att", "conv_3.bias"), ("att", "conv_4.weigh
 
 def _grad_rtol(tag, key):
     """Relative bar of one gradient tensor against the REFERENCE's own fp32 gradient (tests/golden/step.npz).
-    Measured on the MI355X (scratch/diag_step_grads.py, B = 16, N = 64, W = 3): the reference's fp32 gradients sit 1e-3 .. 5e-3
+    Measured on the MI355X (tests/diagnostics/diag_step_grads.py, B = 16, N = 64, W = 3): the reference's fp32 gradients sit 1e-3 .. 5e-3
     (bn_5.bias: 1.3e-2) from a float64 evaluation of the same graph on EVERY tensor whose value depends on a T-Net -- the encoder
     and, through the global features, the attention and conv_2 of the head -- and so does any other fp32 evaluation (torch's own:
     same figures).  Only the last two head layers are free of that noise: there the HIP gradients agree with the reference to

@@ -1,5 +1,5 @@
 """A/B of the pipelined fp32 K loop of pw_gemm (AMPNET_PW_PIPE=1) against the plain form, interleaved in ONE process on ONE box
-(boxes differ by several per cent on MFMA-bound kernels): python3 scratch/ab_pw_pipe.py"""
+(boxes differ by several per cent on MFMA-bound kernels): python3 tools/ab_pw_pipe.py"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""Per-forward view of a rocprofv3 kernel_stats.csv of scratch/prof_fwd.py N: python3 scratch/fwd_stats.py <csv> N [top]"""
+"""Per-forward view of a rocprofv3 kernel_stats.csv of tools/prof_fwd.py N: python3 tools/fwd_stats.py <csv> N [top]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]); top = int(sys.argv[3]) if len(sys.argv) > 3 else 40

@@ -1,5 +1,5 @@
 // Does fp32 VALU work overlap with v_mfma_f32_32x32x2_f32 on gfx950?  (and with v_mfma_f32_32x32x16_bf16?)
-// hipcc --offload-arch=gfx950 -O3 -o scratch/mfma_probe scratch/mfma_probe.hip
+// hipcc --offload-arch=gfx950 -O3 -o tools/mfma_probe tools/mfma_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,4 +1,4 @@
-"""FPS + k-NN only (BASELINE configs[4]: 16 clouds x 8192 -> 4096, k = 32), for rocprofv3 passes: python3 scratch/prof_fps.py [reps]"""
+"""FPS + k-NN only (BASELINE configs[4]: 16 clouds x 8192 -> 4096, k = 32), for rocprofv3 passes: python3 tools/prof_fps.py [reps]"""
 import importlib, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

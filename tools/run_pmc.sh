@@ -5,8 +5,8 @@ set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-P="python3 $GRAFT_REPO_ROOT/scratch/prof_step.py 2"
-F="python3 $GRAFT_REPO_ROOT/scratch/prof_fps.py 2"
+P="python3 $GRAFT_REPO_ROOT/tools/prof_step.py 2"
+F="python3 $GRAFT_REPO_ROOT/tools/prof_fps.py 2"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/train/mfma -- $P > $OUT/mfma.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/train/sq -- $P > $OUT/sq.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/train/FETCH_SIZE -- $P > $OUT/fetch.log 2>&1 &&

@@ -1,4 +1,4 @@
-"""Per-step view of a rocprofv3 kernel_stats.csv of scratch/prof_step.py: launches per step, share of the < 100 us kernels."""
+"""Per-step view of a rocprofv3 kernel_stats.csv of tools/prof_step.py: launches per step, share of the < 100 us kernels."""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 60

@@ -1,5 +1,5 @@
 // Probe of ds_read_b64_tr_b16 + v_mfma_f32_32x32x16_bf16 operand maps as pw_bwd_bf16.hip uses them (run on the MI355X):
-//   hipcc --offload-arch=gfx950 -O2 scratch/tr_probe.hip -o scratch/tr_probe && scratch/tr_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/tr_probe.hip -o tools/tr_probe && tools/tr_probe
 // C[m][n] = sum_k G[k][m] * Y[k][n] with G, Y row-major [16][32] bf16 tiles read transposed must equal the host product.
 #include <hip/hip_runtime.h>
 #include <cstdio>
