@@ -372,12 +372,14 @@ def _baseline_two_steps(tr, mk, base, Bn, N, res, sfx):
             g = p.grad.detach().double()
             res[f"s{step}_gnorm{sfx}/{k}"] = np.array([g.norm().item(), g.sum().item()])
             if p.numel() <= 2048:
-                res[f"s{step}_grad{sfx}/{k}"] = p.grad.detach().numpy()
+                res[f"s{step}_grad{sfx}/{k}"] = p.grad.detach().numpy().astype(np.float32)
+            else:                                   # every stride-th element (<= 1024 of them): the float32-to-float64 distance of large tensors
+                res[f"s{step}_gsample{sfx}/{k}"] = p.grad.detach().reshape(-1)[::-(-p.numel() // 1024)].numpy().astype(np.float32)
             if full:
                 res[f"s{step}_psum/{k}"] = np.array([p.detach().double().sum().item(), p.detach().double().abs().sum().item()])
         for k, v in net.state_dict().items():
             if "running" in k:
-                res[f"s{step}_buf{sfx}/{k}"] = v.numpy().copy()
+                res[f"s{step}_buf{sfx}/{k}"] = v.numpy().astype(np.float32)
     np.random.seed(2109)
     with torch.no_grad():
         data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
@@ -420,27 +422,38 @@ def sec_baseline_cls():
         with torch.no_grad():
             out, ft = net(torch.from_numpy(synth.windows(84, 4, 512)))
         res["eval_out"], res["eval_feat_T"] = out.numpy(), ft.numpy()
-        net = mk(0.0)
-        net.load_state_dict(state, strict=False)
-        net.train()
-        x = torch.from_numpy(synth.windows(85, 16, 512))
         y = torch.from_numpy((synth.uniform(86, (16,), 0.0, 1.0) * n_cls).astype(np.int64).clip(0, n_cls - 1))
-        out, ft = net(x)
-        nll = torch.nn.functional.nll_loss(out, y)
-        reg = torch.norm(torch.eye(64) - torch.bmm(ft, ft.transpose(2, 1)))
-        (nll + 0.001 * reg).backward()
-        res.update(train_out=out.detach().numpy(), train_feat_T=ft.detach().numpy(), labels=y.numpy(), nll=np.array([nll.item()]), reg=np.array([reg.item()]))
-        for k, p in net.named_parameters():
-            g = p.grad.detach()
-            res[f"gnorm/{k}"] = np.array([g.double().norm().item(), g.double().sum().item()])
-            if g.numel() <= 16384:
-                res[f"grad/{k}"] = g.numpy()
-            else:                                   # large tensors: norm + sum above and every stride-th element (<= 4096 of them)
-                stride = -(-g.numel() // 4096)
-                res[f"gsample/{k}"] = g.reshape(-1)[::stride].numpy().copy()
-        for k, v in net.state_dict().items():
-            if "running" in k:
-                res[f"buf/{k}"] = v.numpy().copy()
+        res["labels"] = y.numpy()
+        # the train step twice: as the reference runs it (float32) and with torch's default dtype float64 (suffix 64: the arbiter; the
+        # distance between the two is the reference's own float32 noise on this graph)
+        for sfx, dt in (("", torch.float32), ("64", torch.float64)):
+            torch.set_default_dtype(dt)
+            try:
+                net = mk(0.0)
+                net.load_state_dict(state, strict=False)
+                net.train()
+                x = torch.from_numpy(synth.windows(85, 16, 512)).to(dt)
+                out, ft = net(x)
+                nll = torch.nn.functional.nll_loss(out, y)
+                reg = torch.norm(torch.eye(64) - torch.bmm(ft, ft.transpose(2, 1)))
+                (nll + 0.001 * reg).backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
+            res.update({f"nll{sfx}": np.array([nll.item()]), f"reg{sfx}": np.array([reg.item()])})
+            if sfx == "":
+                res.update(train_out=out.detach().numpy(), train_feat_T=ft.detach().numpy())
+            for k, p in net.named_parameters():
+                g = p.grad.detach()
+                res[f"gnorm{sfx}/{k}"] = np.array([g.double().norm().item(), g.double().sum().item()])
+                if g.numel() <= 4096:
+                    res[f"grad{sfx}/{k}"] = g.numpy().astype(np.float32)
+                else:                               # large tensors: norm + sum above and every stride-th element (<= 2048 of them)
+                    stride = -(-g.numel() // 2048)
+                    res[f"gsample{sfx}/{k}"] = g.reshape(-1)[::stride].numpy().astype(np.float32)
+            if sfx == "":
+                for k, v in net.state_dict().items():
+                    if "running" in k:
+                        res[f"buf/{k}"] = v.numpy().copy()
         save(tag, seed_base=np.array([base]), **res)
 
 

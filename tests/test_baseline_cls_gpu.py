@@ -3,8 +3,8 @@ tape of csrc/baseline_train.hip, against outputs of the reference MODULES themse
 baseline_light_cls.npz, made by tests/golden/make_golden.py:sec_baseline_cls; the reference's classification DRIVERS cannot run as
 committed, DESIGN.md section 7, so the modules are what is pinned).
 Bars: eval log-probabilities / feature transform 1e-4 absolute; train-mode (dropout 0, B = 16) loss terms 1e-4 relative, outputs 1e-3,
-running statistics 1e-3, every gradient within 3e-2 of its norm + 1e-5 of the total (B = 16 rows in the FC BatchNorms: the reference's
-own float32 autograd sits 1e-2 .. 2e-2 from float64 on the input T-Net's tensors; the float64 check below arbitrates at the same bar); dropout 0.3 against a float64 restatement with the same keep-mask."""
+running statistics 1e-3, every gradient within 3 x (the reference's own float32-to-float64 distance, both runs in the fixture) + 2e-2 of its
+norm of the reference's float64 gradient (B = 16 rows in the FC BatchNorms make the input T-Net's tensors noisy in the reference itself); dropout 0.3 against a float64 restatement with the same keep-mask."""
 import os
 import sys
 
@@ -76,26 +76,30 @@ def test_train_step_matches_reference_autograd(golden, synth, tag, modname, pdim
             np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == 1
-    gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith("gnorm/")))
+    # arbiter = the reference's own float64 run of this step (make_golden.py: default dtype float64); a gradient may sit no further from it
+    # than 3 x the reference's float32 run does + 2e-2 of its norm (B = 16 rows in the FC BatchNorms: the input T-Net's tensors are the
+    # noisy ones, in the reference as here)
+    gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith("gnorm64/")))
     bad, worst = [], 0.0
     for k, p in net.named_parameters():
         assert p.grad is not None, k
-        got = p.grad.detach().cpu().double().numpy()
-        ref_norm = float(g[f"gnorm/{k}"][0])
-        tol = 3e-2 * ref_norm + 1e-5 * gtot
-        if abs(np.linalg.norm(got) - ref_norm) > tol:
-            bad.append((k, "norm", float(np.linalg.norm(got)), ref_norm))
-        if f"grad/{k}" in g.files:
-            err = np.linalg.norm(got - g[f"grad/{k}"].astype(np.float64))
+        got = p.grad.detach().cpu().double().numpy().reshape(-1)
+        n64 = float(g[f"gnorm64/{k}"][0])
+        floor = 2e-2 * n64 + 1e-5 * gtot
+        if f"grad64/{k}" in g.files:
+            r32, r64, mine, scale = g[f"grad/{k}"].astype(np.float64).reshape(-1), g[f"grad64/{k}"].astype(np.float64).reshape(-1), got, 1.0
         else:                                                    # large tensors: every stride-th element, scaled to the whole tensor
-            sample = g[f"gsample/{k}"].astype(np.float64)
-            stride = -(-got.size // 4096)
-            err = np.linalg.norm(got.reshape(-1)[::stride] - sample) * np.sqrt(stride)
-        worst = max(worst, err / (ref_norm + 1e-5 * gtot))
-        if err > tol:
-            bad.append((k, "grad", float(err), ref_norm))
+            stride = -(-got.size // 2048)
+            r32, r64, mine, scale = g[f"gsample/{k}"].astype(np.float64), g[f"gsample64/{k}"].astype(np.float64), got[::stride], np.sqrt(stride)
+        noise = np.linalg.norm(r32 - r64) * scale
+        err = np.linalg.norm(mine - r64) * scale
+        worst = max(worst, err / (n64 + 1e-5 * gtot))
+        if err > 3.0 * noise + floor:
+            bad.append((k, "grad", float(err), float(noise), n64))
+        if abs(np.linalg.norm(got) - n64) > 3.0 * noise + floor:
+            bad.append((k, "norm", float(np.linalg.norm(got)), n64))
     assert not bad, bad
-    print(f"{tag}: worst relative gradient error vs the reference's autograd {worst:.2e}")
+    print(f"{tag}: worst relative distance of a gradient from the reference's float64 autograd {worst:.2e}")
 
 
 def _f64_forward(sd, x, pdim, drop_keep, drop_p):

@@ -145,19 +145,24 @@ def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
             bad.append((step, "preds", mism, self_mism))
         gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith(f"s{step}_gnorm64/")))
         for k, p in net.named_parameters():
-            n32, n64 = float(g[f"s{step}_gnorm/{k}"][0]), float(g[f"s{step}_gnorm64/{k}"][0])
-            got = p.grad.double()
+            n64 = float(g[f"s{step}_gnorm64/{k}"][0])
+            got = p.grad.double().cpu().numpy().reshape(-1)
             floor = 2e-2 * n64 + 1e-5 * gtot
-            if abs(got.norm().item() - n64) > 3.0 * abs(n32 - n64) + floor:
-                bad.append((step, "gnorm", k, got.norm().item(), n64, n32))
-            key = f"s{step}_grad64/{k}"
-            if key in g.files:
-                noise = np.linalg.norm(g[f"s{step}_grad/{k}"].astype(np.float64) - g[key])
-                err = np.linalg.norm(got.cpu().numpy() - g[key])
-                worst[step] = max(worst[step], err / (n64 + 1e-5 * gtot))
-                tight2 += int(step == 2 and 3.0 * noise < floor)
-                if err > 3.0 * noise + floor:
-                    bad.append((step, "grad", k, float(err), float(noise), n64))
+            if f"s{step}_grad64/{k}" in g.files:                  # stored in full
+                r32, r64, scale = g[f"s{step}_grad/{k}"].astype(np.float64).reshape(-1), g[f"s{step}_grad64/{k}"].astype(np.float64).reshape(-1), 1.0
+                mine = got
+            else:                                                 # large tensor: every stride-th element stands for the whole
+                stride = -(-got.size // 1024)
+                r32, r64 = g[f"s{step}_gsample/{k}"].astype(np.float64), g[f"s{step}_gsample64/{k}"].astype(np.float64)
+                mine, scale = got[::stride], np.sqrt(stride)
+            noise = np.linalg.norm(r32 - r64) * scale             # the reference's own float32-to-float64 distance on this tensor
+            err = np.linalg.norm(mine - r64) * scale
+            worst[step] = max(worst[step], err / (n64 + 1e-5 * gtot))
+            tight2 += int(step == 2 and 3.0 * noise < floor)
+            if err > 3.0 * noise + floor:
+                bad.append((step, "grad", k, float(err), float(noise), n64))
+            if abs(np.linalg.norm(got) - n64) > 3.0 * noise + floor:      # |‖a‖ - ‖b‖| <= ‖a - b‖: the same yardstick bounds the norm
+                bad.append((step, "gnorm", k, float(np.linalg.norm(got)), n64, float(noise)))
         sd = net.state_dict()
         rt_buf = 1e-3 if step == 1 else 2e-2
         for k in sd:
@@ -167,7 +172,7 @@ def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
                 if d > rt_buf * max(1.0, np.abs(ref).max()):
                     bad.append((step, "buf", k, float(d)))
     assert not bad, bad[:12]
-    print(f"{variant} B=16: worst relative distance of the gradients stored in full from the reference's float64 run: step 1 {worst[1]:.2e}, "
+    print(f"{variant} B=16: worst relative distance of a gradient tensor from the reference's float64 run: step 1 {worst[1]:.2e}, "
           f"step 2 {worst[2]:.2e}; {tight2} step-2 tensors carry the plain 2e-2 bar")
     np.random.seed(2109)
     with torch.no_grad():
