@@ -22,7 +22,9 @@ struct PwInputWgrad {
 int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st);
 int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
                       float *dT, hipStream_t st);
-int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, int by_workgroup, hipStream_t st);
-int fill_f32(float *p, size_t n, float v, hipStream_t st);   // sums `chunks` partials per window   // dst[p(q)] = src[q]^T, 64 x 64
+// dst[p(q)] = (sum of the window's `chunks` partials)^T (+ add[p(q)]), 64 x 64, p(q) = the slot-major row of window q
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, int by_workgroup, const float *add, hipStream_t st);
+int fill_f32(float *p, size_t n, float v, hipStream_t st);
+int fill_f32_pair(float *p0, float v0, float *p1, float v1, size_t n, hipStream_t st);
 
 }  // namespace ampnet

@@ -9,14 +9,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ----------------------------------------------------------------------------------------------------
 // bn_bwd_finalize: block = (slot, 64 channels) x 4 groups over the slot's partials, fixed order
 // ----------------------------------------------------------------------------------------------------
-constexpr int BFIN_G = 16;
-
-__global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinalize a)
+// CPB channels per block x (1024 / CPB) groups over the partials: 64 x 16 by default; 16 x 64 when there are few (slot, 64-channel) blocks
+// and many partials (the head: one slot, 64 channels, one partial per workgroup of head_out_bwd -- 49 us in ONE block before)
+template <int CPB>
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdFinalize a)
 {
-    __shared__ double ra[BFIN_G][64], rb[BFIN_G][64];
+    constexpr int BFIN_G = 1024 / CPB;
+    __shared__ double ra[BFIN_G][CPB], rb[BFIN_G][CPB];
     __shared__ int rows_s;
-    const int slot = blockIdx.x, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
+    const int slot = blockIdx.x, cl = threadIdx.x % CPB, g = threadIdx.x / CPB;
+    const int c = blockIdx.y * CPB + cl;
     const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
     const int part_per_slot = a.part_Q > 0 ? (a.part_Q - slot + a.n_slots - 1) / a.n_slots : per_slot;
     double sa = 0.0, sb = 0.0;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinal
         if (threadIdx.x == 0) rows_s = per_slot * a.uniform_rows;
     } else {
         int rows = 0;
-        for (int i = threadIdx.x; i < per_slot; i += 64 * BFIN_G) {
+        for (int i = threadIdx.x; i < per_slot; i += 1024) {
             const int q = slot + i * a.n_slots;
             rows += a.win_off[q + 1] - a.win_off[q];
         }
@@ -76,8 +78,12 @@ __global__ __launch_bounds__(64 * BFIN_G) void bn_bwd_finalize_kernel(BnBwdFinal
 
 int bn_bwd_finalize(const BnBwdFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_a && a.part_b && a.win_off && a.gamma && a.mean && a.invstd && a.P1 && a.P2 && a.P3 && a.slot_ab, "bn_bwd_finalize: null pointer");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.n_slots, cdiv(a.C, 64)), dim3(64 * BFIN_G), 0, st, a);
+    AMPNET_REQUIRE(a.part_a && a.part_b && (a.win_off || a.uniform_rows > 0) && a.gamma && a.mean && a.invstd && a.P1 && a.P2 && a.P3 && a.slot_ab, "bn_bwd_finalize: null pointer");
+    const long parts = (long)(a.part_Q > 0 ? cdiv(a.part_Q, a.n_slots) : cdiv(a.Q, a.n_slots)) * a.chunks;
+    if (a.n_slots * cdiv(a.C, 64) < 8 && parts >= 512)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3(a.n_slots, cdiv(a.C, 16)), dim3(1024), 0, st, a);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3(a.n_slots, cdiv(a.C, 64)), dim3(1024), 0, st, a);
     int rc = check_launch("bn_bwd_finalize_kernel");
     if (rc == AMPNET_OK && sync_bn_on())       // global batch: the constants again, from the all-reduced sums (slot_ab stays the rank's own)
         rc = sync_bn_bwd_constants(a.slot_ab, a.win_off, a.Q, a.n_slots, a.uniform_rows, a.C, a.gamma, nullptr, a.mean, a.invstd, a.P1, a.P2, a.P3, st);
@@ -207,6 +213,10 @@ struct SgProblem {
     int M, N, K, ta, tb, lda, ldb, ldc, accumulate;
     const float *A, *B;
     float *C;
+    // B(k, n) = relu(B(k, n) * bs[k / bper][n] + bt[k / bper][n]) while loaded (tb == 0): the T-Net FC activations are never materialised
+    const float *bs = nullptr, *bt = nullptr;
+    int bper = 1;
+    int b_ones = 0;                    // B is all ones (row sums of op(A): a bias gradient G^T 1 as one more problem of the launch, N = 1)
 };
 constexpr int SG_MAX_PROBLEMS = 10;
 struct SgArgs {
@@ -235,7 +245,12 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
             ra[i] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
             const int n = TB ? e / 32 : e % 32, k2 = TB ? e % 32 : e / 32;
             const int gn = n0 + n, gk2 = k0 + k2;
-            rb[i] = (gn < N && gk2 < K) ? (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn]) : 0.f;
+            float bv = (gn < N && gk2 < K) ? (g.b_ones ? 1.0f : (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn])) : 0.f;
+            if (g.bs && gn < N && gk2 < K) {
+                const size_t so = (size_t)(gk2 / g.bper) * N + gn;
+                bv = fmaxf(fmaf(bv, g.bs[so], g.bt[so]), 0.f);
+            }
+            rb[i] = bv;
         }
     };
     auto stash = [&]() {
@@ -300,7 +315,8 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < n; ++i) {
         const SgProblem &p = probs[i];
-        AMPNET_REQUIRE(p.A && p.B && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "sgemm_small: bad arguments");
+        AMPNET_REQUIRE(p.A && (p.B || p.b_ones) && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "sgemm_small: bad arguments");
+        AMPNET_REQUIRE(!p.bs || (p.bt && p.tb == 0 && p.bper >= 1), "sgemm_small: the fused activation is built for a row-major B");
         a.p[i] = p;
         gx = cdiv(p.N, 32) > gx ? cdiv(p.N, 32) : gx;
         gy = cdiv(p.M, 32) > gy ? cdiv(p.M, 32) : gy;
@@ -316,32 +332,58 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                 int accumulate, hipStream_t st)
 {
-    const SgProblem p = {M, N, K, transA, transB, lda, ldb, ldc, accumulate, A, B, C};
+    SgProblem p = {M, N, K, transA, transB, lda, ldb, ldc, accumulate, A, B, C};
     return sgemm_launch(&p, 1, st);
+}
+
+// weight gradient + bias gradient of the LAST layer of a chain (no data gradient wanted): dW [n_out, n_in] = G^T X, db [n_out] = column sums of G
+int sgemm_wgrad_bias(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, float *dW, int lddw, float *db, hipStream_t st)
+{
+    SgProblem p[2];
+    p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
+    p[1] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, db};      // db [n_out, 1] = G^T 1: the grid shape of the dW problem
+    p[1].b_ones = 1;
+    return sgemm_launch(p, db ? 2 : 1, st);
 }
 
 // the weight gradient dW = G^T X ([N_out, N_in] = [rows, N_out]^T [rows, N_in]) and the data gradient dX = G W of one linear layer
 // on [rows, *] activations, one launch (the two products are independent)
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
-                     float *dX, int lddx, hipStream_t st)
+                     float *dX, int lddx, hipStream_t st, const LinBwdOpt &o)
 {
-    const SgProblem p[2] = {{n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW}, {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX}};
-    return sgemm_launch(p, 2, st);
+    SgProblem p[3];
+    p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
+    p[0].bs = o.xs; p[0].bt = o.xt; p[0].bper = o.x_per > 0 ? o.x_per : 1;
+    p[1] = {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX};
+    int n = 2;
+    if (o.db) {                                  // the bias gradient: ones^T G, one more problem of the same launch
+        p[2] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, o.db};
+        p[2].b_ones = 1;
+        n = 3;
+    }
+    return sgemm_launch(p, n, st);
 }
 
 // the same for a layer with thousands of outputs (the feature T-Net's fc_3: 128 -> 4096): dX = G W has few output tiles and a K of n_out, so
 // one workgroup per tile walks 128 k tiles in sequence (114 us for 1.2 GFLOP).  The K range is cut into `splits` problems of the same
 // launch, each writing its own partial [rows, n_in]; a fixed-order reduction adds them (no atomics: reproducible).
 int sgemm_linear_bwd_ksplit(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW,
-                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st)
+                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st, const LinBwdOpt &o)
 {
-    AMPNET_REQUIRE(scratch && splits >= 2 && splits < SG_MAX_PROBLEMS && n_out % splits == 0, "sgemm_linear_bwd_ksplit: %d outputs in %d splits", n_out, splits);
+    AMPNET_REQUIRE(scratch && splits >= 2 && splits + 2 <= SG_MAX_PROBLEMS && n_out % splits == 0, "sgemm_linear_bwd_ksplit: %d outputs in %d splits", n_out, splits);
     SgProblem p[SG_MAX_PROBLEMS];
     p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
+    p[0].bs = o.xs; p[0].bt = o.xt; p[0].bper = o.x_per > 0 ? o.x_per : 1;
     const int kc = n_out / splits;
     for (int c = 0; c < splits; ++c)
         p[1 + c] = {rows, n_in, kc, 0, 0, ldg, ldw, n_in, 0, G + (size_t)c * kc, W + (size_t)c * kc * ldw, scratch + (size_t)c * rows * n_in};
-    int rc = sgemm_launch(p, 1 + splits, st);
+    int np = 1 + splits;
+    if (o.db) {
+        p[np] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, o.db};
+        p[np].b_ones = 1;
+        ++np;
+    }
+    int rc = sgemm_launch(p, np, st);
     if (rc != AMPNET_OK) return rc;
     return reduce_windows(scratch, splits, (long)rows * n_in, rows, n_in, n_in, dX, lddx, 0, st);
 }
@@ -624,6 +666,22 @@ int fill_f32(float *p, size_t n, float v, hipStream_t st)
     return check_launch("fill_kernel");
 }
 
+__global__ void fill_pair_kernel(float *__restrict__ p0, float v0, float *__restrict__ p1, float v1, size_t n)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        p0[i] = v0;
+        p1[i] = v1;
+    }
+}
+
+// two constant arrays of n floats in one launch
+int fill_f32_pair(float *p0, float v0, float *p1, float v1, size_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(fill_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p0, v0, p1, v1, n);
+    return check_launch("fill_pair_kernel");
+}
+
 int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
 {
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, alpha, n, y);
@@ -636,7 +694,8 @@ int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st)
 
 namespace ampnet {
 // dst[p(q)] = src[q]^T with p(q) the slot-major row of window q
-__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots, int chunks, int by_workgroup)
+__global__ __launch_bounds__(256) void transpose64_kernel(const float *__restrict__ src, float *__restrict__ dst, int Q, int n_slots, int chunks, int by_workgroup,
+                                                          const float *__restrict__ add)
 {
     __shared__ float t[64][65];
     const int q = blockIdx.x;
@@ -651,12 +710,13 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const float *__restric
         t[e / 64][e % 64] = s;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 4096; e += 256) dst[p * 4096 + e] = t[e % 64][e / 64];
+    // + add (same layout as dst): the gradient that reaches the transforms from outside (the regulariser), no separate axpy launch
+    for (int e = threadIdx.x; e < 4096; e += 256) dst[p * 4096 + e] = t[e % 64][e / 64] + (add ? add[p * 4096 + e] : 0.f);
 }
 
-int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, int by_workgroup, hipStream_t st)
+int transpose64_slot_major(const float *src, float *dst, int Q, int n_slots, int chunks, int by_workgroup, const float *add, hipStream_t st)
 {
-    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots, chunks, by_workgroup);
+    hipLaunchKernelGGL(transpose64_kernel, dim3(Q), dim3(256), 0, st, src, dst, Q, n_slots, chunks, by_workgroup, add);
     return check_launch("transpose64_kernel");
 }
 }  // namespace ampnet

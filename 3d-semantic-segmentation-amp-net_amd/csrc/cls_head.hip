@@ -215,13 +215,12 @@ extern "C" int ampnet_cls_head_fwd_f32(const float *const *params_host, float *c
     const float *const *P = params_host;
     const int Q = B * W;
     const float dp = train ? drop_p : 0.f;
-    TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     auto tok_gemm = [&](const float *A, const float *Wm, const float *bias, int cout, float *Z) {
         PwGemm g;
         g.A = A; g.lda = 256; g.cin = 256;
         g.W = Wm; g.ldw = 256; g.bias = bias;
         g.Z = Z; g.ldz = cout; g.cout = cout;
-        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = 128; g.chunks = cdiv(Q, 128); g.rows_hint = Q;
+        g.uniform_rows = Q; g.Q = 1; g.chunk_rows = 128; g.chunks = cdiv(Q, 128); g.rows_hint = Q;
         return pw_gemm(g, st);
     };
     TRY(tok_gemm(gl, P[CP_INPROJ_W], P[CP_INPROJ_B], 768, ws.qkv));

@@ -37,7 +37,7 @@ struct EncWs {
     float *pool_t, *z_tf1, *z_tf2, *T3, *pool_f, *z_ff1, *z_ff2;
     int *arg_t, *arg_f, *arg_c;        // [Q, 256] row index of the pooled extreme
     float *zext_t, *zext_f, *zext_c;   // [Q, 256] its pre-BatchNorm value (all the backward needs of the 256-channel layers)
-    int *fc_off;                       // [n_slots + 1]
+    int *part_rows;                    // [1024] rows covered by each per-workgroup statistics partial (pw_gemm_stat_plan)
     float *merge;                      // two-stage bn_finalize scratch
     float *part_sum, *part_sq, *part_max;   // [Q * chunks, 256]
     int *part_amax;
@@ -46,6 +46,9 @@ struct EncWs {
 };
 
 EncShape enc_shape(int Q, int n_slots, int R, int max_rows, int train);
+// the backward keeps two alternating regions of BatchNorm-backward partials in part_sum / part_sq: one per fused workgroup (<= 320 + n_slots)
+// + one per window (the scattered rows of the pooled layers), 256 channels wide
+inline size_t enc_bwd_part_region_floats(const EncShape &s) { return (size_t)(320 + s.n_slots + s.Q) * 256; }
 // carve the workspace; base may be nullptr to only compute ws.bytes
 void enc_carve(const EncShape &s, void *base, EncWs &ws);
 

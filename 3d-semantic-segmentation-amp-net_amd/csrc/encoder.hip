@@ -89,11 +89,12 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.zext_t = c.take<float>(Q * 256);
     ws.zext_f = c.take<float>(Q * 256);
     ws.zext_c = c.take<float>(Q * 256);
-    ws.fc_off = c.take<int>((size_t)s.n_slots + 1);
+    ws.part_rows = c.take<int>(2048 + (size_t)s.n_slots);
     ws.merge = c.take<float>(bn_finalize_merge_floats(s.n_slots, 256));     // two-stage bn_finalize scratch
     const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
     // the fused backward indexes its BatchNorm sums by workgroup (<= 256 + n_slots of them) + one row per window
-    const size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256;
+    const size_t two_regions = 2 * enc_bwd_part_region_floats(s);
+    const size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256 > two_regions ? np + (size_t)(320 + s.n_slots) * 256 : two_regions;
     ws.part_sum = c.take<float>(np_bwd);
     ws.part_sq = c.take<float>(np_bwd);
     ws.part_max = c.take<float>(np);
@@ -158,10 +159,17 @@ struct EncRun {
         if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
         if (pool) { g.part_max = ws.part_max; g.part_amax = ws.part_amax; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
+        if (stats && !pool) {                                    // one partial per workgroup: bn_finalize in one stage (kernels.h)
+            g.part_rows = ws.part_rows;
+            g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots).lanes;
+        }
         return g;
     }
     // FC layer on the pooled rows: n_slots windows of Q / n_slots rows (one window of Q rows in eval mode)
-    PwGemm fc_layer(const float *A, int cin, const float *W, int cout, const float *bias, int pro_bn, float *Z, int ldz, bool stats) const
+    // stats_bn >= 0: this layer's BatchNorm.  A slot's rows are one block of rows when fc_chunks == 1 (B <= 128): the workgroup then writes
+    // the BatchNorm constants itself and finalize_fc() launches nothing.  Not under global-batch BatchNorm (the ranks' partials are merged).
+    bool fc_direct() const { return s.train && s.fc_chunks == 1 && !sync_bn_on(); }
+    PwGemm fc_layer(const float *A, int cin, const float *W, int cout, const float *bias, int pro_bn, float *Z, int ldz, int stats_bn) const
     {
         PwGemm g;
         g.A = A; g.lda = cin; g.cin = cin;
@@ -169,20 +177,37 @@ struct EncRun {
         if (pro_bn >= 0) { g.pro_scale = ws.bn[pro_bn].scale; g.pro_shift = ws.bn[pro_bn].shift; }
         g.n_slots = s.train ? s.n_slots : 1;
         g.Z = Z; g.ldz = ldz; g.cout = cout;
-        if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
-        g.win_off = ws.fc_off; g.Q = s.n_slots; g.chunk_rows = s.fc_chunk_rows; g.chunks = s.fc_chunks; g.rows_hint = s.Q;
+        g.uniform_rows = s.fc_rows; g.Q = s.n_slots; g.chunk_rows = s.fc_chunk_rows; g.chunks = s.fc_chunks; g.rows_hint = s.Q;
+        if (stats_bn >= 0 && s.train) {
+            g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; g.part_rows = ws.part_rows;
+            g.stat_lanes = pw_gemm_stat_plan(g.Q, g.chunks, g.n_slots).lanes;
+            if (fc_direct()) {
+                const BnSlot &b = ws.bn[stats_bn];
+                g.fin_gamma = bnp[stats_bn].gamma; g.fin_beta = bnp[stats_bn].beta;
+                g.fin_scale = b.scale; g.fin_shift = b.shift; g.fin_mean = b.mean; g.fin_invstd = b.invstd; g.fin_smean = b.smean; g.fin_suvar = b.suvar;
+            }
+        }
         return g;
     }
-    int finalize(int bn, bool fc) const
+    // wg: the producer left one partial per workgroup (point layers without pool, FC layers); otherwise one per (window, chunk)
+    // lanes: the producer left `lanes` per-workgroup partials (default: pw_gemm's plan); 0: one per (window, chunk) (the pooled layers)
+    int finalize(int bn, bool fc, int lanes = -1) const
     {
         if (!s.train) return AMPNET_OK;
+        if (fc && fc_direct()) return AMPNET_OK;                 // the FC GEMM wrote the constants itself
         BnFinalize f;
         f.part_sum = ws.part_sum; f.part_sq = ws.part_sq;
-        f.win_off = fc ? ws.fc_off : win_off;
+        f.win_off = win_off;
         f.Q = fc ? s.n_slots : s.Q;
         f.chunks = fc ? s.fc_chunks : s.chunks;
         f.chunk_rows = fc ? s.fc_chunk_rows : s.chunk_rows;
         f.uniform_rows = fc ? s.fc_rows : ((long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0);
+        if (lanes != 0) {
+            f.part_rows = ws.part_rows;
+            f.Q = cdiv(lanes > 0 ? lanes : pw_gemm_stat_plan(f.Q, f.chunks, s.n_slots).lanes, s.n_slots) * s.n_slots;    // partial slots (kernels.h: PwStatPlan.parts)
+            f.chunks = 1;
+            f.uniform_rows = 0;
+        }
         f.n_slots = s.n_slots; f.C = ws.bn[bn].C;
         f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
         f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;
@@ -218,23 +243,28 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
         in.x = x_or_A; in.W = e.P[pbase + TP_CONV1]; in.mode = 0; in.Z = z1; in.z_bf16 = e.zb ? 1 : 0;
         if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
         in.win_off = e.win_off; in.Q = e.s.Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
+        if (tr) { in.part_rows = e.ws.part_rows; in.stat_lanes = pw_input_stat_lanes(e.s.Q, e.s.chunks, e.s.n_slots); in.n_slots = e.s.n_slots; }
         TRY(pw_input(in, e.st));
+        TRY(e.finalize(bn0 + 0, false, in.stat_lanes));
     } else {
         TRY(pw_gemm(e.point_layer(x_or_A, 64, e.P[pbase + TP_CONV1], 64, pro0, z1, tr, false), e.st));
+        TRY(e.finalize(bn0 + 0, false));
     }
-    TRY(e.finalize(bn0 + 0, false));
     TRY(pw_gemm(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), e.st));
     TRY(e.finalize(bn0 + 1, false));
     TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true, bn0 + 2), e.st));
-    TRY(e.finalize(bn0 + 2, false));
+    TRY(e.finalize(bn0 + 2, false, 0));
     TRY(e.pool(bn0 + 2, pooled, arg, zext, true));
     // FC head on [Q, 256]
-    TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, tr), e.st));
+    TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, bn0 + 3), e.st));
     TRY(e.finalize(bn0 + 3, true));
-    TRY(pw_gemm(e.fc_layer(zf1, 256, e.P[pbase + TP_FC2], 128, nullptr, bn0 + 3, zf2, 128, tr), e.st));
+    TRY(pw_gemm(e.fc_layer(zf1, 256, e.P[pbase + TP_FC2], 128, nullptr, bn0 + 3, zf2, 128, bn0 + 4), e.st));
     TRY(e.finalize(bn0 + 4, true));
-    TRY(pw_gemm(e.fc_layer(zf2, 128, e.P[pbase + TP_FC3_W], k * k, e.P[pbase + TP_FC3_B], bn0 + 4, T, k * k, false), e.st));
-    TRY(add_identity(T, e.s.Q, k, e.st));
+    {
+        PwGemm g = e.fc_layer(zf2, 128, e.P[pbase + TP_FC3_W], k * k, e.P[pbase + TP_FC3_B], bn0 + 4, T, k * k, -1);
+        g.identity_k = k;                                        // + I (pointnetAtt.py:42-46) in the GEMM's bias, no extra launch
+        TRY(pw_gemm(g, e.st));
+    }
     return AMPNET_OK;
 }
 
@@ -272,7 +302,6 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     const bool tr = train != 0;
     if (tr) ws_tag_set(workspace, matrix_precision());      // the backward checks it ran in the same precision mode
 
-    TRY(fill_i32_ramp(e.ws.fc_off, e.s.n_slots + 1, e.s.fc_rows, e.st));
     if (!tr) {
         BnFoldItem items[BN_ENC_COUNT];
         for (int i = 0; i < BN_ENC_COUNT; ++i)
@@ -289,8 +318,9 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
         in.perwin_slot_major = tr ? 1 : 0; in.n_slots = e.s.n_slots; in.Z = e.ws.z_c1; in.z_bf16 = e.zb ? 1 : 0;
         if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
         in.win_off = win_off; in.Q = Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
+        if (tr) { in.part_rows = e.ws.part_rows; in.stat_lanes = pw_input_stat_lanes(Q, e.s.chunks, e.s.n_slots); }
         TRY(pw_input(in, e.st));
-        TRY(e.finalize(BN_C1, false));
+        TRY(e.finalize(BN_C1, false, in.stat_lanes));
     }
     TRY(pw_gemm(e.point_layer(e.ws.z_c1, 64, e.P[EP_CONV2], 64, BN_C1, e.ws.z_c2, tr, false), e.st));
     TRY(e.finalize(BN_C2, false));
@@ -310,7 +340,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(pw_gemm(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), e.st));
     TRY(e.finalize(BN_C5, false));
     TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true, BN_C6), e.st));
-    TRY(e.finalize(BN_C6, false));
+    TRY(e.finalize(BN_C6, false, 0));
     TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, e.ws.zext_c, false));
 
     if (tr) {

@@ -116,6 +116,34 @@ struct EncBwd {
     size_t wpart_cap = 0;
     mutable ReduceItem deferred[REDUCE_MULTI_MAX];
     mutable int n_deferred = 0;
+    // BatchNorm-backward sums: every producer writes its partials (sum dy, sum dy zhat) into one of TWO regions of the forward
+    // workspace's partial arrays, alternating, and the constants of that layer are owed: the next fused layer forms them itself from the
+    // region the producer wrote (PwBwd.fin_*: no bn_bwd_finalize launch) while it writes its own partials into the other region;
+    // consumers that are not the fp32 fused kernel get the launch (settle()).
+    struct Owed {
+        bool open = false;
+        int bn = -1, C = 0, parts = 0, chunks = 1;
+        const float *pa = nullptr, *pb = nullptr;
+    };
+    mutable Owed owed;
+    mutable int part_region = 0;
+    bool in_kernel_fin = false;      // fp32 fused kernel, uniform windows, no global-batch BatchNorm
+    size_t region_floats() const { return enc_bwd_part_region_floats(s); }
+    float *part_a_out() const { return f.part_sum + (size_t)part_region * region_floats(); }
+    float *part_b_out() const { return f.part_sq + (size_t)part_region * region_floats(); }
+    int settle() const            // launch the finalize that is still owed (its consumer cannot do it in-kernel)
+    {
+        if (!owed.open) return AMPNET_OK;
+        owed.open = false;
+        BnBwdFinalize fz;
+        fz.part_a = owed.pa; fz.part_b = owed.pb; fz.win_off = win_off;
+        fz.Q = s.Q; fz.chunks = owed.chunks; fz.part_Q = owed.parts; fz.n_slots = s.n_slots; fz.C = owed.C;
+        fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
+        const int bn = owed.bn;
+        fz.gamma = gamma[bn]; fz.mean = f.bn[bn].mean; fz.invstd = f.bn[bn].invstd;
+        fz.P1 = b.bn[bn].P1; fz.P2 = b.bn[bn].P2; fz.P3 = b.bn[bn].P3; fz.slot_ab = b.bn[bn].slot_ab;
+        return bn_bwd_finalize(fz, st);
+    }
     int flush_deferred() const
     {
         if (n_deferred == 0) return AMPNET_OK;
@@ -186,6 +214,7 @@ struct EncBwd {
     int layer_bwd(const GradSrc &g, const float *W, float *dW, const float *prev_z, int prev_bn, int cy, const float *add, float *out) const
     {
         if (!fused || !pw_bwd_supported(g.C, cy)) {
+            TRY(settle());                    // the separate kernels read the constants from memory
             ActSrc y;
             if (prev_bn >= 0) y = act(prev_z, prev_bn, cy);
             else { y.z = prev_z; y.C = cy; }
@@ -195,10 +224,21 @@ struct EncBwd {
         }
         PwBwd p;
         p.g = g;
+        // the constants of the layer g belongs to: formed inside this launch when they are still owed (and g is that layer), else launched now
+        if (owed.open && in_kernel_fin && g.P1 == b.bn[owed.bn].P1 && owed.chunks == 1) {
+            p.fin_part_a = owed.pa; p.fin_part_b = owed.pb; p.fin_parts = owed.parts;
+            p.fin_rows = (s.Q / s.n_slots) * s.max_rows;
+            p.fin_gamma = gamma[owed.bn]; p.fin_mean = f.bn[owed.bn].mean; p.fin_invstd = f.bn[owed.bn].invstd;
+            p.fin_P1 = b.bn[owed.bn].P1; p.fin_P2 = b.bn[owed.bn].P2; p.fin_P3 = b.bn[owed.bn].P3; p.fin_slot_ab = b.bn[owed.bn].slot_ab;
+            owed.open = false;
+            part_region ^= 1;                 // this launch writes the other region
+        } else {
+            TRY(settle());
+        }
         if (prev_bn >= 0) {
             p.prev = act(prev_z, prev_bn, cy);
             p.prev_mean = f.bn[prev_bn].mean; p.prev_invstd = f.bn[prev_bn].invstd;
-            p.part_a = f.part_sum; p.part_b = f.part_sq;
+            p.part_a = part_a_out(); p.part_b = part_b_out();
         } else {
             p.prev.z = prev_z; p.prev.C = cy;
         }
@@ -218,18 +258,17 @@ struct EncBwd {
         } else {
             TRY(reduce_windows(part, nblk, (long)g.C * cy, g.C, cy, cy, dW, cy, 0, st));
         }
-        if (prev_bn >= 0) TRY(finalize_prev(prev_bn, cy, nblk, 1));
+        if (prev_bn >= 0) TRY(finalize_prev(prev_bn, cy, nblk, 1, p.part_a, p.part_b));
         return AMPNET_OK;
     }
-    int finalize_prev(int prev_bn, int cp, int part_Q, int chunks) const
+    // the partials (pa, pb) of layer prev_bn are complete: its constants are owed to the next consumer
+    int finalize_prev(int prev_bn, int cp, int part_Q, int chunks, const float *pa, const float *pb) const
     {
-        BnBwdFinalize fz;
-        fz.part_a = f.part_sum; fz.part_b = f.part_sq; fz.win_off = win_off;
-        fz.Q = s.Q; fz.chunks = chunks; fz.part_Q = part_Q; fz.n_slots = s.n_slots; fz.C = cp;
-        fz.uniform_rows = (long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0;
-        fz.gamma = gamma[prev_bn]; fz.mean = f.bn[prev_bn].mean; fz.invstd = f.bn[prev_bn].invstd;
-        fz.P1 = b.bn[prev_bn].P1; fz.P2 = b.bn[prev_bn].P2; fz.P3 = b.bn[prev_bn].P3; fz.slot_ab = b.bn[prev_bn].slot_ab;
-        return bn_bwd_finalize(fz, st);
+        TRY(settle());
+        owed.open = true; owed.bn = prev_bn; owed.C = cp; owed.parts = part_Q > 0 ? part_Q : s.Q * chunks; owed.chunks = part_Q > 0 ? chunks : chunks;
+        owed.pa = pa; owed.pb = pb;
+        if (part_Q <= 0 || chunks != 1) return settle();      // per-(window, chunk) partials of the unfused path: finalize now
+        return AMPNET_OK;
     }
     // Backward of a 128 -> 256 layer followed by BatchNorm + ReLU + MaxPool, WITHOUT its [rows, 256] output.
     // With z = W a, dz = P1 dy + P2 z + P3 and dy non-zero only on the argmax rows (kernels.h, "backward of a max-pooled
@@ -272,7 +311,8 @@ struct EncBwd {
             const int nblk = p.blocks_per_slot * s.n_slots;
             if (wpart_used + (size_t)nblk * 128 * 128 > wpart_cap) TRY(flush_deferred());       // the Gram partials go behind the deferred regions
             float *gpart = b.wpart + wpart_used;
-            p.out = dy_out; p.dWpart = gpart; p.dbpart = b.dbpart; p.part_a = f.part_sum; p.part_b = f.part_sq;
+            TRY(settle());                    // (nothing is owed at the points this is called from; cheap insurance)
+            p.out = dy_out; p.dWpart = gpart; p.dbpart = b.dbpart; p.part_a = part_a_out(); p.part_b = part_b_out();
             p.win_off = win_off; p.Q = s.Q; p.n_slots = s.n_slots; p.max_rows = s.max_rows; p.rows_hint = s.R;
             TRY(pw_bwd_fused(p, st));
             TRY(reduce_slots2(gpart, 128 * 128, b.gram, b.dbpart, 128, b.asum, nblk, 1, s.n_slots, st));
@@ -283,10 +323,10 @@ struct EncBwd {
             ss.z_prev = z_prev; ss.s_prev = f.bn[prev_bn].scale; ss.t_prev = f.bn[prev_bn].shift; ss.z_bf16 = zb ? 1 : 0;
             ss.mean_prev = f.bn[prev_bn].mean; ss.invstd_prev = f.bn[prev_bn].invstd;
             ss.Q = s.Q; ss.n_slots = s.n_slots; ss.out = dy_out;
-            ss.part_a = f.part_sum + (size_t)nblk * 128; ss.part_b = f.part_sq + (size_t)nblk * 128;
+            ss.part_a = p.part_a + (size_t)nblk * 128; ss.part_b = p.part_b + (size_t)nblk * 128;
             ss.part_chunks = 1; ss.slot_idx = 0;
             TRY(sparse_scatter(ss, st));
-            return finalize_prev(prev_bn, 128, nblk + s.Q, 1);
+            return finalize_prev(prev_bn, 128, nblk + s.Q, 1, p.part_a, p.part_b);
         }
         // Gram and column sums of a = relu(bn_prev(z_prev)) per slot, then dW
         {
@@ -315,25 +355,27 @@ struct EncBwd {
         sf.part_a = f.part_sum; sf.part_b = f.part_sq;
         sf.part_chunks = s.chunks + 1; sf.slot_idx = s.chunks;
         TRY(sparse_fix(sf, st));
-        return finalize_prev(prev_bn, 128, 0, s.chunks + 1);
+        return finalize_prev(prev_bn, 128, 0, s.chunks + 1, f.part_sum, f.part_sq);
     }
 
     // T-Net FC head backward: g3 [Q, kk] (slot-major rows) -> parameter grads, d_pool [Q, 256]
     int tnet_fc_bwd(int pbase, int bn0, const float *g3, int kk, const float *pooled, const float *zf1, const float *zf2) const
     {
         const int Q = s.Q, per = s.fc_rows, ns = s.n_slots;
-        TRY(fc_act(zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, Q, 256, per, b.a1, st));
-        TRY(fc_act(zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, Q, 128, per, b.a2, st));
+        // the activations a1 = relu(bn_4(zf1)), a2 = relu(bn_5(zf2)) are rebuilt while the weight-gradient GEMMs load them (LinBwdOpt.xs / xt);
+        // fc_3's bias gradient rides in the same launch as its two GEMMs
+        LinBwdOpt o3, o2;
+        o3.xs = f.bn[bn0 + 4].scale; o3.xt = f.bn[bn0 + 4].shift; o3.x_per = per; o3.db = G[pbase + TP_FC3_B];
+        o2.xs = f.bn[bn0 + 3].scale; o2.xt = f.bn[bn0 + 3].shift; o2.x_per = per;
         // fc_3: z3 = a2 W3^T + b3
         if (kk >= 1024)
-            TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st));
+            TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, zf2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st, o3));
         else
-            TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st));
-        TRY(colsum(g3, Q, kk, G[pbase + TP_FC3_B], st));
+            TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, zf2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st, o3));
         TRY(fc_bn_bwd(b.da2, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per, 128, b.g2,
                       b.bn[bn0 + 4].slot_ab, st));
         // fc_2
-        TRY(sgemm_linear_bwd(Q, 128, 256, b.g2, 128, b.a1, 256, P[pbase + TP_FC2], 256, G[pbase + TP_FC2], 256, b.da1, 256, st));
+        TRY(sgemm_linear_bwd(Q, 128, 256, b.g2, 128, zf1, 256, P[pbase + TP_FC2], 256, G[pbase + TP_FC2], 256, b.da1, 256, st, o2));
         TRY(fc_bn_bwd(b.da1, zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per, 256, b.g1,
                       b.bn[bn0 + 3].slot_ab, st));
         // fc_1 on the pooled features
@@ -380,6 +422,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     }
     e.zb = z_storage_bf16();
     AMPNET_REQUIRE(!e.zb || e.fused, "ampnet_encoder_bwd_f32: bf16 activation storage needs the fused backward");
+    {
+        const char *env = getenv("AMPNET_BWD_FIN_IN_KERNEL");
+        e.in_kernel_fin = e.fused && !bwd_operands_bf16() && !sync_bn_on() && (long)max_rows * Q == (long)total_rows && !(env && env[0] == '0');
+    }
     e.wpart_cap = e.fused ? ((size_t)Q * (size_t)wg_chunks(e.s) + 320 + n_slots) * 256 * 128 : 0;      // floats in b.wpart (enc_bwd_carve)
     const float *const *P = params_host;
     float *const *G = grads_host;
@@ -431,8 +477,8 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
             // one pass over (d_local, z_c2): dT^T[j][k] = sum_rows d_local[row][j] h[row][k] per window AND
             // d_h[row][k] = sum_j d_local[row][j] T[k][j] (masked by conv_2's ReLU here already: the mask is idempotent and the
             // feature T-Net's conv_1 backward applies it again after adding its own term).  g = dy via identity constants.
-            TRY(fill_f32(b.ones64, (size_t)n_slots * 64, 1.0f, st));
-            TRY(fill_f32(b.zeros64, (size_t)n_slots * 64, 0.0f, st));
+            TRY(e.settle());
+            TRY(fill_f32_pair(b.ones64, 1.0f, b.zeros64, 0.0f, (size_t)n_slots * 64, st));
             PwBwd p;
             p.g.dy = b.d_local; p.g.z = b.d_local; p.g.C = 64; p.g.P1 = b.ones64; p.g.P2 = b.zeros64; p.g.P3 = b.zeros64;
             p.prev = e.act(f.z_c2, BN_C2, 64);
@@ -441,8 +487,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
             p.win_off = win_off; p.Q = Q; p.n_slots = n_slots; p.max_rows = max_rows; p.rows_hint = total_rows;
             p.items_per_block = ipb; p.blocks_per_slot = (Q / n_slots) * bpw;
             TRY(pw_bwd_fused(p, st));
-            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, bpw, 1, st));
-            if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
+            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, bpw, 1, d_feat_T, st));
         } else {
             PwWgrad w;                                   // dT^T[j][k] = sum_rows d_local[row][j] * h[row][k]
             w.x = e.dense(b.d_local, nullptr, -1, 64);
@@ -452,8 +497,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
             w.chunk_rows = e.s.chunk_rows; w.chunks = e.s.chunks;      // several workgroups per window: no half-empty last round
             TRY(pw_wgrad(w, st));
             // window q's matrix (sum of its chunk partials) belongs at the slot-major row the forward used for feat_T
-            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, e.s.chunks, 0, st));
-            if (d_feat_T) TRY(axpy(d_feat_T, 1.0f, (size_t)Q * 4096, b.dT64, st));
+            TRY(transpose64_slot_major(b.dT64t, b.dT64, Q, n_slots, e.s.chunks, 0, d_feat_T, st));
             PwDgrad d;                                   // d_h[row][k] = sum_j d_local[row][j] * T[k][j]
             d.g = e.dense(b.d_local, nullptr, -1, 64);
             d.W = feat_T; d.w_win_stride = 4096; d.perwin_slot_major = 1;
@@ -479,6 +523,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(e.layer_bwd(g, P[EP_CONV2], G[EP_CONV2], f.z_c1, BN_C1, 64, nullptr, b.dyB));
     }
     {
+        TRY(e.settle());                       // pw_input_wgrad reads bn_1's constants from memory
         PwInputWgrad w;
         w.x = x; w.dy = b.dyB; w.z = f.z_c1; w.z_bf16 = e.zb ? 1 : 0;
         w.P1 = b.bn[BN_C1].P1; w.P2 = b.bn[BN_C1].P2; w.P3 = b.bn[BN_C1].P3;
@@ -494,6 +539,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(e.layer_bwd(g, P[EP_IT + TP_CONV2], G[EP_IT + TP_CONV2], f.z_t1, BN_T1, 64, nullptr, b.dyB));
     }
     {
+        TRY(e.settle());
         PwInputWgrad w;
         w.x = x; w.dy = b.dyB; w.z = f.z_t1; w.z_bf16 = e.zb ? 1 : 0;
         w.P1 = b.bn[BN_T1].P1; w.P2 = b.bn[BN_T1].P2; w.P3 = b.bn[BN_T1].P3;
@@ -501,6 +547,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(pw_input_wgrad(w, st));
         TRY(input_param_grads(b.dWeff, P[EP_IT + TP_CONV1], nullptr, Q, n_slots, 0, 0, G[EP_IT + TP_CONV1], nullptr, st));
     }
+    TRY(e.settle());
     TRY(e.flush_deferred());           // every fused layer's weight gradient: one reduction launch
     // ---- BatchNorm weight / bias gradients: sums over the slots of (sum dy, sum dy * zhat) -----------------------------
     {

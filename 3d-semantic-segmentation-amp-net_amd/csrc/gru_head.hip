@@ -153,13 +153,12 @@ extern "C" int ampnet_gru_head_fwd_f32(const float *const *params_host, float *c
     const int Q = s.Q;
     if (tr) ws_tag_set(workspace, matrix_precision());
 
-    TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     auto tok_gemm = [&](const float *A, int cin, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
         PwGemm g;
         g.A = A; g.lda = cin; g.cin = cin;
         g.W = Wm; g.ldw = ldw; g.bias = bias;
         g.Z = Z; g.ldz = cout; g.cout = cout;
-        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks; g.rows_hint = Q;
+        g.uniform_rows = Q; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks; g.rows_hint = Q;
         return pw_gemm(g, st);
     };
     TRY(tok_gemm(gl, 256, P[GP_WIH], 256, P[GP_BIH], G3, ws.qkv));                              // gi = W_ih x + b_ih, all steps at once

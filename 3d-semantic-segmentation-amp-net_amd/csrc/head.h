@@ -33,7 +33,7 @@ struct HeadWs {
     // GRU:       qkv = gi [Q,192] (W_ih x + b_ih), ctx = gates [Q,4,64] (r, z, n, W_hn h + b_hn), g2 = h [Q,64]; tok / probs unused
     float *tok, *qkv, *probs, *ctx, *g2, *gbias;   // gbias [Q,128]: token half of conv_2 + its bias, one row per window
     float *z2, *z3;                                // [R,128] [R,64]
-    int *tok_off;                                  // [2] = {0, Q}
+    int *part_rows;                                // [1024] rows per per-workgroup statistics partial (PwGemm.part_rows)
     float *part_sum, *part_sq;                     // [max(Q*chunks, tok_chunks), 128]
     float *merge;                                  // two-stage bn_finalize scratch
     float *loss_part;                              // [blocks, 2]

@@ -71,7 +71,7 @@ void head_carve(const HeadShape &s, void *base, HeadWs &ws)
     ws.gbias = c.take<float>(Q * 128);
     ws.z2 = c.take<float>(R * 128);
     ws.z3 = c.take<float>(R * 64);
-    ws.tok_off = c.take<int>(2);
+    ws.part_rows = c.take<int>(1024);
     const size_t np = (Q * (size_t)s.chunks > (size_t)s.tok_chunks ? Q * (size_t)s.chunks : (size_t)s.tok_chunks) * 128;
     ws.part_sum = c.take<float>(np);
     ws.part_sq = c.take<float>(np);
@@ -109,8 +109,8 @@ int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, co
     auto finalize = [&](BnSlot1 &b, const float *gamma, const float *beta) {
         BnFinalize f;
         f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.chunk_rows = s.chunk_rows;
-        f.win_off = win_off; f.Q = Q; f.chunks = s.chunks; f.n_slots = 1; f.C = b.C;
-        f.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+        f.win_off = win_off; f.n_slots = 1; f.C = b.C;
+        f.part_rows = ws.part_rows; f.Q = pw_gemm_stat_plan(Q, s.chunks, 1).parts; f.chunks = 1;      // one partial per workgroup
         f.gamma = gamma; f.beta = beta;
         f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd; f.stat_mean = b.smean; f.stat_uvar = b.suvar;
         f.merge_ws = ws.merge;
@@ -122,7 +122,7 @@ int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, co
         g.W = p.conv2_w; g.ldw = p.conv2_ld;
         g.bias = ws.gbias; g.bias_win_stride = 128;
         g.Z = ws.z2; g.ldz = 128; g.cout = 128; g.z_bf16 = zb;
-        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; g.part_rows = ws.part_rows; g.stat_lanes = pw_gemm_stat_plan(Q, s.chunks, 1).lanes; }
         g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
         if (tr) TRY(finalize(ws.bn2, p.bn2_w, p.bn2_b));
@@ -134,7 +134,7 @@ int head_points_fwd(const HeadShape &s, HeadWs &ws, const HeadPointParams &p, co
         g.pro_scale = ws.bn2.scale; g.pro_shift = ws.bn2.shift;
         g.drop_p = dp; g.drop_seed = drop_base(seed, 1);
         g.Z = ws.z3; g.ldz = 64; g.cout = 64; g.z_bf16 = zb;
-        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        if (tr) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; g.part_rows = ws.part_rows; g.stat_lanes = pw_gemm_stat_plan(Q, s.chunks, 1).lanes; }
         g.win_off = win_off; g.Q = Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = total_rows;
         TRY(pw_gemm(g, st));
         if (tr) TRY(finalize(ws.bn3, p.bn3_w, p.bn3_b));
@@ -205,14 +205,13 @@ static int head_fwd_impl(const float *const *params_host, float *const *buffers_
     const int Q = s.Q;
     if (tr) ws_tag_set(workspace, matrix_precision());
 
-    TRY(fill_i32_ramp(ws.tok_off, 2, Q, st));
     TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
     auto tok_gemm = [&](const float *A, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
         PwGemm g;
         g.A = A; g.lda = 256; g.cin = 256;
         g.W = Wm; g.ldw = ldw; g.bias = bias;
         g.Z = Z; g.ldz = cout; g.cout = cout;
-        g.win_off = ws.tok_off; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks; g.rows_hint = Q;
+        g.uniform_rows = Q; g.Q = 1; g.chunk_rows = s.tok_chunk_rows; g.chunks = s.tok_chunks; g.rows_hint = Q;
         return pw_gemm(g, st);
     };
     TRY(tok_gemm(ws.tok, P[HP_INPROJ_W], 256, P[HP_INPROJ_B], 768, ws.qkv));

@@ -282,7 +282,14 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
     const int blocks = cdiv(R, HB_ROWS);
     const int wch = cdiv(max_rows, 1024);
     const int zb = z_storage_bf16() ? 1 : 0;         // z2 / z3 of this forward workspace are bf16 tensors (precision mode 3)
-    TRY(fill_i32_ramp(b.tot_off, 2, R, st));
+    // the parameter-gradient partials of the three layers stay in their regions of wpart / dbpart / w4part and are reduced by ONE launch at
+    // the end (seven reduce_windows launches before)
+    ReduceItem red[REDUCE_MULTI_MAX];
+    int n_red = 0;
+    // BatchNorm-backward constants inside the consuming fused kernel (PwBwd.fin_*) instead of two bn_bwd_finalize launches: fp32 fused path only
+    const char *fenv0 = getenv("AMPNET_FUSED_BWD"), *kenv = getenv("AMPNET_BWD_FIN_IN_KERNEL");
+    const bool fin_in_kernel = !(fenv0 && fenv0[0] == '0') && !(kenv && kenv[0] == '0') && !bwd_operands_bf16() && !sync_bn_on();
+    float *pa3 = b.part_a + align_up((size_t)blocks * 64, 64), *pb3 = b.part_b + align_up((size_t)blocks * 64, 64);   // conv_3's partials: behind head_out_bwd's
     // ---- conv_4 + dropout + bn_3/ReLU mask ------------------------------------------------------------
     {
         HeadOutBwd o;
@@ -293,14 +300,16 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
         o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
         hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
         TRY(check_launch("head_out_bwd_kernel"));
-        TRY(reduce_windows(b.w4part, blocks, C * 64 + C, 1, C * 64, C * 64, g.conv4_w, C * 64, 0, st));
-        TRY(reduce_windows(b.w4part + C * 64, blocks, C * 64 + C, 1, C, C, g.conv4_b, C, 0, st));
-        BnBwdFinalize fz;
-        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = b.tot_off; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
-        fz.uniform_rows = R;
-        fz.gamma = p_.bn3_w; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
-        fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
-        TRY(bn_bwd_finalize(fz, st));
+        red[n_red++] = ReduceItem{b.w4part, blocks, (long)(C * 64 + C), 1, C * 64, C * 64, g.conv4_w, C * 64};
+        red[n_red++] = ReduceItem{b.w4part + C * 64, blocks, (long)(C * 64 + C), 1, C, C, g.conv4_b, C};
+        if (!fin_in_kernel) {                    // else conv_3's fused backward forms bn_3's constants from these partials itself
+            BnBwdFinalize fz;
+            fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = nullptr; fz.Q = 1; fz.chunks = blocks; fz.n_slots = 1; fz.C = 64;
+            fz.uniform_rows = R;
+            fz.gamma = p_.bn3_w; fz.mean = f.bn3.mean; fz.invstd = f.bn3.invstd;
+            fz.P1 = b.P1[1]; fz.P2 = b.P2[1]; fz.P3 = b.P3[1]; fz.slot_ab = b.slot_ab[1];
+            TRY(bn_bwd_finalize(fz, st));
+        }
     }
     // ---- conv_3: z3 = dropout(relu(bn_2(z2))) W3^T + b3 --------------------------------------------------
     GradSrc g3;
@@ -309,26 +318,44 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
     a2.z = f.z2; a2.C = 128; a2.z_bf16 = zb; a2.s = f.bn2.scale; a2.t = f.bn2.shift; a2.drop_p = drop_p; a2.drop_seed = drop_base(seed, 1);
     const char *fenv = getenv("AMPNET_FUSED_BWD");
     const bool fused = !(fenv && fenv[0] == '0');
+    size_t conv3_w_floats = 0, conv3_b_floats = 0;             // conv_3's partial regions (fused path): conv_2's go behind them
+    int conv3_parts = 0;                                       // > 0: bn_2's constants are still owed (conv_2's fused kernel forms them)
     AMPNET_REQUIRE(!zb || fused, "ampnet_head_bwd_f32: bf16 activation storage needs the fused backward");
     if (fused) {
         // one pass over (dy3, z3, z2): weight + bias gradient partials and dy2 with bn_2's backward sums
         PwBwd p;
         p.g = g3; p.prev = a2; p.prev_mean = f.bn2.mean; p.prev_invstd = f.bn2.invstd;
         p.W = p_.conv3_w; p.ldw = 128; p.out = b.dy2; p.dWpart = b.wpart; p.dbpart = b.dbpart;
-        p.part_a = b.part_a; p.part_b = b.part_b;
+        p.part_a = fin_in_kernel ? pa3 : b.part_a; p.part_b = fin_in_kernel ? pb3 : b.part_b;
         p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
         p.blocks_per_slot = pw_bwd_blocks(Q, 1, max_rows);
         const int nblk = p.blocks_per_slot;
+        if (fin_in_kernel) {
+            p.fin_part_a = b.part_a; p.fin_part_b = b.part_b; p.fin_parts = blocks; p.fin_rows = R;
+            p.fin_gamma = p_.bn3_w; p.fin_mean = f.bn3.mean; p.fin_invstd = f.bn3.invstd;
+            p.fin_P1 = b.P1[1]; p.fin_P2 = b.P2[1]; p.fin_P3 = b.P3[1]; p.fin_slot_ab = b.slot_ab[1];
+        }
         TRY(pw_bwd_fused(p, st));
-        TRY(reduce_windows(b.wpart, nblk, 64 * 128, 64, 128, 128, g.conv3_w, 128, 0, st));
-        TRY(reduce_windows(b.dbpart, nblk, 64, 1, 64, 64, g.conv3_b, 64, 0, st));
-        BnBwdFinalize fz;
-        fz.part_a = b.part_a; fz.part_b = b.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = 1; fz.part_Q = nblk; fz.n_slots = 1; fz.C = 128;
-        fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
-        fz.gamma = p_.bn2_w; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
-        fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
-        TRY(bn_bwd_finalize(fz, st));
+        red[n_red++] = ReduceItem{b.wpart, nblk, 64L * 128, 64, 128, 128, g.conv3_w, 128};
+        red[n_red++] = ReduceItem{b.dbpart, nblk, 64L, 1, 64, 64, g.conv3_b, 64};
+        conv3_w_floats = align_up((size_t)nblk * 64 * 128, 64);
+        conv3_b_floats = align_up((size_t)nblk * 64, 64);
+        conv3_parts = nblk;
+        const int cpw2 = cdiv(max_rows, pw_bwd_item_rows());
+        int ipb2 = cpw2 < 4 ? cpw2 : 4;
+        while (cpw2 % ipb2) --ipb2;
+        if (!(fin_in_kernel && cpw2 / ipb2 <= wch)) {          // conv_2 will not run the fused kernel (or not in-kernel): bn_2's constants by launch
+            BnBwdFinalize fz;
+            fz.part_a = p.part_a; fz.part_b = p.part_b; fz.win_off = win_off; fz.Q = Q; fz.chunks = 1; fz.part_Q = nblk; fz.n_slots = 1; fz.C = 128;
+            fz.uniform_rows = (long)max_rows * Q == (long)total_rows ? max_rows : 0;
+            fz.gamma = p_.bn2_w; fz.mean = f.bn2.mean; fz.invstd = f.bn2.invstd;
+            fz.P1 = b.P1[0]; fz.P2 = b.P2[0]; fz.P3 = b.P3[0]; fz.slot_ab = b.slot_ab[0];
+            TRY(bn_bwd_finalize(fz, st));
+            conv3_parts = 0;
+        }
     } else {
+        if (n_red) TRY(reduce_windows_multi(red, n_red, st));
+        n_red = 0;
         PwWgrad w;
         w.x = g3; w.y = a2; w.dWpart = b.wpart; w.ldp = 128; w.dbpart = b.dbpart;
         w.win_off = win_off; w.Q = Q; w.n_slots = 1; w.rows_hint = R; w.chunk_rows = 1024; w.chunks = wch;
@@ -360,14 +387,22 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
     if (fused && bpw <= wch) {
         PwBwd p;
         p.g = g2; p.prev.z = lo; p.prev.C = 64;
-        p.W = p_.conv2_w; p.ldw = p_.conv2_ld; p.out = d_lo; p.dWpart = b.wpart; p.dbpart = b.dbpart;
+        float *wp2 = b.wpart + conv3_w_floats, *dbp2 = b.dbpart + conv3_b_floats;
+        p.W = p_.conv2_w; p.ldw = p_.conv2_ld; p.out = d_lo; p.dWpart = wp2; p.dbpart = dbp2;
         p.win_off = win_off; p.Q = Q; p.n_slots = 1; p.max_rows = max_rows; p.rows_hint = R;
         p.items_per_block = ipb; p.blocks_per_slot = Q * bpw;
+        if (conv3_parts > 0) {
+            p.fin_part_a = pa3; p.fin_part_b = pb3; p.fin_parts = conv3_parts; p.fin_rows = R;
+            p.fin_gamma = p_.bn2_w; p.fin_mean = f.bn2.mean; p.fin_invstd = f.bn2.invstd;
+            p.fin_P1 = b.P1[0]; p.fin_P2 = b.P2[0]; p.fin_P3 = b.P3[0]; p.fin_slot_ab = b.slot_ab[0];
+        }
         TRY(pw_bwd_fused(p, st));
-        TRY(reduce_windows(b.wpart, Q * bpw, 128 * 64, 128, 64, 64, g.conv2_w, g.conv2_ld, 0, st));
-        TRY(reduce_windows(b.dbpart, bpw, 128, Q, 128, bpw * 128, b.dgb, 128, 0, st));
-        TRY(reduce_windows(b.dgb, Q, 128, 1, 128, 128, g.conv2_b, 128, 0, st));
+        red[n_red++] = ReduceItem{wp2, Q * bpw, 128L * 64, 128, 64, 64, g.conv2_w, g.conv2_ld};
+        red[n_red++] = ReduceItem{dbp2, bpw, 128L, Q, 128, bpw * 128, b.dgb, 128};       // per window: the gradient of its token bias
+        red[n_red++] = ReduceItem{dbp2, Q * bpw, 128L, 1, 128, 128, g.conv2_b, 128};      // all of them: conv_2.bias
     } else {
+        if (n_red) TRY(reduce_windows_multi(red, n_red, st));     // wpart / dbpart are about to be reused from their start
+        n_red = 0;
         ActSrc yl;
         yl.z = lo; yl.C = 64;
         PwWgrad w;
@@ -383,6 +418,7 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
         d.win_off = win_off; d.Q = Q; d.n_slots = 1; d.chunk_rows = s.chunk_rows; d.chunks = s.chunks; d.rows_hint = R;
         TRY(pw_dgrad(d, st));
     }
+    if (n_red) TRY(reduce_windows_multi(red, n_red, st));
     // ---- BatchNorm weight / bias gradients ---------------------------------------------------------------------------
     {
         BnGradItem items[2] = {{b.slot_ab[0], g.bn2_w, g.bn2_b, 128, 1}, {b.slot_ab[1], g.bn3_w, g.bn3_b, 64, 1}};
@@ -435,19 +471,27 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
     // ---- token path: gbias = g2tok W2[:, 64:]^T + b2 ; g2tok = ctx Wo^T + bo ; qkv = tok Wi^T + bi -------------
     const float *d_gbias = b.dgb;                                                           // [Q, 128]
     TRY(sgemm_linear_bwd(Q, 128, 256, d_gbias, 128, f.g2, 256, P[HP_CONV2_W] + 64, 320, G[HP_CONV2_W] + 64, 320, b.d_g2, 256, st));
-    TRY(sgemm_linear_bwd(Q, 256, 256, b.d_g2, 256, f.ctx, 256, P[HP_OUTPROJ_W], 256, G[HP_OUTPROJ_W], 256, b.d_ctx, 256, st));
-    TRY(colsum(b.d_g2, Q, 256, G[HP_OUTPROJ_B], st));
+    {
+        LinBwdOpt o;
+        o.db = G[HP_OUTPROJ_B];
+        TRY(sgemm_linear_bwd(Q, 256, 256, b.d_g2, 256, f.ctx, 256, P[HP_OUTPROJ_W], 256, G[HP_OUTPROJ_W], 256, b.d_ctx, 256, st, o));
+    }
     TRY(attention_core_bwd(f.qkv, f.probs, b.d_ctx, b.d_qkv, B, W, drop_p, drop_base(seed, 0), st));
-    TRY(sgemm_linear_bwd(Q, 768, 256, b.d_qkv, 768, f.tok, 256, P[HP_INPROJ_W], 256, G[HP_INPROJ_W], 256, d_gl, 256, st));   // d_tok = d_gl = d_pos
-    TRY(colsum(b.d_qkv, Q, 768, G[HP_INPROJ_B], st));
+    {
+        LinBwdOpt o;
+        o.db = G[HP_INPROJ_B];
+        TRY(sgemm_linear_bwd(Q, 768, 256, b.d_qkv, 768, f.tok, 256, P[HP_INPROJ_W], 256, G[HP_INPROJ_W], 256, d_gl, 256, st, o));   // d_tok = d_gl = d_pos
+    }
     // ---- positional encoding: pos = leaky(cent W1^T + b1) W2^T + b2 --------------------------------------------
     hipLaunchKernelGGL(posenc_hidden_kernel, dim3(cdiv(Q * 16, 64)), dim3(64), 0, st, centroids, P[HP_FC1_W], P[HP_FC1_B], Q, b.hid, b.slope);
     TRY(check_launch("posenc_hidden_kernel"));
-    TRY(sgemm_linear_bwd(Q, 256, 16, d_gl, 256, b.hid, 16, P[HP_FC2_W], 16, G[HP_FC2_W], 16, b.d_hid, 16, st));
-    TRY(colsum(d_gl, Q, 256, G[HP_FC2_B], st));
+    {
+        LinBwdOpt o;
+        o.db = G[HP_FC2_B];
+        TRY(sgemm_linear_bwd(Q, 256, 16, d_gl, 256, b.hid, 16, P[HP_FC2_W], 16, G[HP_FC2_W], 16, b.d_hid, 16, st, o));
+    }
     hipLaunchKernelGGL(mul_inplace_kernel, dim3(cdiv(Q * 16, 256)), dim3(256), 0, st, b.d_hid, b.slope, Q * 16);
     TRY(check_launch("mul_inplace_kernel"));
-    TRY(sgemm_small(1, 0, 16, 2, Q, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, 0, st));
-    TRY(colsum(b.d_hid, Q, 16, G[HP_FC1_B], st));
+    TRY(sgemm_wgrad_bias(Q, 16, 2, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, G[HP_FC1_B], st));
     return AMPNET_OK;
 }

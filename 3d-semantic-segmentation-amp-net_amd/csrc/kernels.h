@@ -43,7 +43,46 @@ struct PwGemm {
     int chunks = 1;                // cdiv(max window rows, chunk_rows)
     long rows_hint = 0;            // total rows (profiling only: algorithmic flops / bytes of the launch)
     int a_bf16 = 0, z_bf16 = 0;    // A / Z are bf16 tensors ([rows, lda] / [rows, ldz] ELEMENTS): activation storage of precision mode 3
+    int uniform_rows = 0;          // > 0: window q is rows q * uniform_rows .. (win_off may be nullptr): no offset array to fill
+    int identity_k = 0;            // > 0: + 1 on the output columns i * (k + 1) (the identity a T-Net adds to its k x k transform)
+    // per-WORKGROUP statistics (not with the pool epilogue): part_rows != nullptr -> part_sum / part_sq are [stat_lanes, cout],
+    // partial `lane` belongs to slot lane % n_slots, part_rows[lane] = rows it covers; stat_lanes from pw_gemm_stat_plan()
+    int *part_rows = nullptr;
+    int stat_lanes = 0;
+    // plan.direct (one block of rows per slot): the workgroup finishes the BatchNorm constants itself, no partial, no bn_finalize launch
+    const float *fin_gamma = nullptr, *fin_beta = nullptr;
+    float *fin_scale = nullptr, *fin_shift = nullptr, *fin_mean = nullptr, *fin_invstd = nullptr, *fin_smean = nullptr, *fin_suvar = nullptr;
+    float fin_eps = 1e-5f;
 };
+struct PwStatPlan {
+    int lanes = 1;                 // workgroups that take part
+    int parts = 1;                 // partial slots they write: (lanes / n_slots rounded up) * n_slots, partial p belongs to slot p % n_slots
+    bool direct = false;
+};
+// Which blocks of rows a lane of the per-workgroup statistics walks.  `lanes` workgroups are dealt to the slots (lanes / n_slots each, one
+// more for the first lanes % n_slots slots); inside a slot lane j takes the blocks j, j + L, ... of the slot's I blocks, so I % L lanes
+// walk one block more than the others.  Lane ids are handed out HEAVY LANES FIRST: with two workgroups per CU (ids c and c + 256) every CU
+// then gets one lane of each kind -- 2304 blocks over 512 lanes are 256 x 5 + 256 x 4, nine per CU, as even as a slot-blind walk.
+struct StatLane {
+    int slot, j, L;                // my slot, my index in it, lanes of that slot
+};
+__device__ __forceinline__ StatLane stat_lane_of(int lane_id, int lanes, int n_slots, int Q, int chunks)
+{
+    const int base = lanes / n_slots, extra = lanes % n_slots;
+    int rem = lane_id;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int s = 0; s < n_slots; ++s) {
+            const int L = base + (s < extra ? 1 : 0);
+            const int I = ((Q - s + n_slots - 1) / n_slots) * chunks;
+            const int h = L > 0 ? (I >= L ? I % L : I) : 0;                 // lanes of slot s that walk one block more
+            const int cnt = pass == 0 ? h : L - h;
+            if (rem < cnt) return StatLane{s, pass == 0 ? rem : h + rem, L};
+            rem -= cnt;
+        }
+    }
+    return StatLane{0, 0, 1};      // not reached for lane_id < lanes
+}
+PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots);
 int pw_gemm(const PwGemm &a, hipStream_t st);
 // one element of an activation tensor that is fp32 or (precision mode 3) bf16
 __device__ __forceinline__ float ld_act(const float *base, size_t elem, int bf16)
@@ -69,9 +108,12 @@ struct PwInput {
     float *Z = nullptr;            // [rows, 64]
     int z_bf16 = 0;                // Z is a bf16 tensor (precision mode 3)
     float *part_sum = nullptr, *part_sq = nullptr;    // [Q * chunks, 64] or nullptr (chunk mean, chunk M2)
+    int *part_rows = nullptr;      // != nullptr: one partial per persistent block, [stat_lanes, 64] + rows (see PwGemm.part_rows)
+    int stat_lanes = 0;
     const int *win_off = nullptr;
     int Q = 0, chunk_rows = 512, chunks = 1;
 };
+int pw_input_stat_lanes(int Q, int chunks, int n_slots);
 int pw_input(const PwInput &a, hipStream_t st);
 
 // BatchNorm statistics -> affine.  One block per (slot, 64 channels).
@@ -257,6 +299,17 @@ struct PwBwd {
     int items_per_block = 0;       // > 0: fixed share of (window, pw_bwd_item_rows()-row chunk) items per workgroup; a divisor of the
                                    // chunks per window keeps every workgroup inside one window (per-window dbpart sums)
     long rows_hint = 0;
+    // Consumer-side BatchNorm-backward constants (fp32 kernel; no bn_bwd_finalize launch between two layers): fin_part_a != nullptr ->
+    // every workgroup sums the fin_parts partials (sum dy, sum dy zhat) [fin_parts, CX] of ITS slot (partial i belongs to slot
+    // i % n_slots) that the producer of g.dy left, in a fixed order, and forms P1..P3 itself (g.P1..P3 are then outputs: the first
+    // workgroup of every slot writes them and slot_ab for the parameter gradients).  The partial arrays must not be the ones this
+    // launch writes (part_a / part_b): the callers alternate two regions.
+    const float *fin_part_a = nullptr, *fin_part_b = nullptr;
+    int fin_parts = 0;
+    int fin_rows = 0;              // rows of one slot (uniform windows)
+    const float *fin_gamma = nullptr, *fin_mean = nullptr, *fin_invstd = nullptr;   // [CX], [n_slots, CX] x2 of the layer g belongs to
+    float *fin_P1 = nullptr, *fin_P2 = nullptr, *fin_P3 = nullptr, *fin_slot_ab = nullptr;
+    int dbg_row_wrap = 0;          // TIMING EXPERIMENT ONLY (AMPNET_PWBWD_ROWWRAP=n): the staging loads read row % n -- wrong results, cache-resident inputs
 };
 int pw_bwd_blocks(int Q, int n_slots, int max_rows);     // blocks_per_slot for this shape (grid = that * n_slots)
 bool pw_bwd_supported(int cx, int cy);
@@ -380,10 +433,16 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st);
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                 int accumulate, hipStream_t st);
 // backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W
+struct LinBwdOpt {
+    float *db = nullptr;                         // [n_out]: the bias gradient (column sums of G) as one more problem of the same launch
+    const float *xs = nullptr, *xt = nullptr;    // [rows / x_per, n_in]: X = relu(X * xs + xt) while loaded (the T-Net FC activations: never materialised)
+    int x_per = 0;
+};
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
-                     float *dX, int lddx, hipStream_t st);
+                     float *dX, int lddx, hipStream_t st, const LinBwdOpt &o = LinBwdOpt());
+int sgemm_wgrad_bias(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, float *dW, int lddw, float *db, hipStream_t st);
 // n_out in the thousands: dX's K range split over `splits` problems of the launch + a fixed-order reduction; scratch [splits, rows, n_in]
 int sgemm_linear_bwd_ksplit(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW,
-                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st);
+                            int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st, const LinBwdOpt &o = LinBwdOpt());
 
 }  // namespace ampnet

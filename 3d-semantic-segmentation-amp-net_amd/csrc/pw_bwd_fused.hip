@@ -12,6 +12,7 @@
 // Workgroups are persistent: (slot, j) walks a contiguous share of the (window, chunk) items of its slot, so the
 // per-workgroup partials are few (grid of them, not windows x chunks), every one belongs to one BatchNorm slot, and
 // weights / constants are staged once.  Fixed assignment, no atomics: bitwise reproducible.
+#include <cstdlib>
 #include <type_traits>
 #include "kernels.h"
 
@@ -86,8 +87,76 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const int stid = tid & (FB_STAGE - 1);
     const int cqx = stid % QX, rsx = stid / QX, cqy = stid % QY, rsy = stid / QY;
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
-    if (has_bn) p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
-    if (has_bn || x_act) {
+    if (has_bn && a.fin_part_a) {
+        // The BatchNorm-backward constants of this layer, formed HERE from the partial sums its producer left (kernels.h): SX groups of
+        // threads split the slot's partials (group gq takes partials gq, gq + SX, ... of the slot, eight loads in flight), double sums, one
+        // fixed-order merge through LDS.  ~30 partials of <= 512 B per workgroup out of L2: noise next to the pass over the rows, and a
+        // launch (5 .. 12 us of an idle chip) less per layer.
+        double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+        const int per_slot_parts = (a.fin_parts - slot + a.n_slots - 1) / a.n_slots;
+        if ((tid < FB_STAGE)) {
+            for (int k0 = rsx; k0 < per_slot_parts; k0 += SX * 8) {
+                f32x4 va[8], vb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + SX * u;
+                    const size_t o = (size_t)(slot + (k < per_slot_parts ? k : 0) * a.n_slots) * CX + 4 * cqx;
+                    va[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_a + o);
+                    vb[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_b + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (k0 + SX * u < per_slot_parts) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            sa[c] += (double)va[u][c];
+                            sb[c] += (double)vb[u][c];
+                        }
+                    }
+                }
+            }
+            double *red = reinterpret_cast<double *>(smem);          // [SX][CX][2]: the staging buffers are not in use yet
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[((size_t)rsx * CX + 4 * cqx + c) * 2 + 0] = sa[c];
+                red[((size_t)rsx * CX + 4 * cqx + c) * 2 + 1] = sb[c];
+            }
+        }
+        __syncthreads();
+        if ((tid < FB_STAGE)) {
+            const double *red = reinterpret_cast<const double *>(smem);
+            const double n = (double)a.fin_rows;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ch = 4 * cqx + c;
+                double A = 0.0, Bs = 0.0;
+                for (int gq = 0; gq < SX; ++gq) {
+                    A += red[((size_t)gq * CX + ch) * 2 + 0];
+                    Bs += red[((size_t)gq * CX + ch) * 2 + 1];
+                }
+                const size_t o = (size_t)slot * CX + ch;
+                const double invstd = a.fin_invstd[o], mean = a.fin_mean[o];
+                const double s = (double)a.fin_gamma[ch] * invstd;
+                const double q2 = -s * invstd * Bs / n;
+                p1[c] = (float)s;
+                p2[c] = (float)q2;
+                p3[c] = (float)(-s * A / n - q2 * mean);
+                if (jb == 0 && rsx == 0) {                       // one writer per slot: the arrays other kernels read
+                    a.fin_slot_ab[o * 2 + 0] = (float)A;
+                    a.fin_slot_ab[o * 2 + 1] = (float)Bs;
+                }
+            }
+            if (jb == 0 && rsx == 0) {
+                *reinterpret_cast<f32x4 *>(a.fin_P1 + (size_t)slot * CX + 4 * cqx) = p1;
+                *reinterpret_cast<f32x4 *>(a.fin_P2 + (size_t)slot * CX + 4 * cqx) = p2;
+                *reinterpret_cast<f32x4 *>(a.fin_P3 + (size_t)slot * CX + 4 * cqx) = p3;
+            }
+        }
+        __syncthreads();                                             // smem is about to be overwritten by the weights / first tile
+    } else if (has_bn) {
+        p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
+    }
+    if ((has_bn && !a.fin_part_a) || x_act) {
         p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
         p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
     }
@@ -130,7 +199,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
-            const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            if (a.dbg_row_wrap) rr %= (size_t)a.dbg_row_wrap;
             if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
             if (has_bn || x_act) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
         }
@@ -138,7 +208,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
             for (int i = 0; i < NIY; ++i) {
                 const int row = p.row0 + rsy + SY * i;
-                const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+                size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+                if (a.dbg_row_wrap) rr %= (size_t)a.dbg_row_wrap;
                 ry_z[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
             }
         }
@@ -530,8 +601,13 @@ static int launch_fused(const PwBwd &a, hipStream_t st)
     return yact ? launch_fused_x<CX, CY, ROWS, false, true, false>(a, st) : launch_fused_x<CX, CY, ROWS, false, false, false>(a, st);
 }
 
-int pw_bwd_fused(const PwBwd &a, hipStream_t st)
+int pw_bwd_fused(const PwBwd &a_in, hipStream_t st)
 {
+    PwBwd a = a_in;
+    {
+        static const int wrap = [] { const char *e = getenv("AMPNET_PWBWD_ROWWRAP"); return e ? atoi(e) : 0; }();
+        a.dbg_row_wrap = wrap;
+    }
     AMPNET_REQUIRE(a.W && a.out && a.dWpart && a.win_off && a.prev.z, "pw_bwd_fused: null pointer");
     AMPNET_REQUIRE(a.g.act ? a.g.z == a.prev.z : (a.g.dy && a.g.P1), "pw_bwd_fused: dense gradient with BatchNorm constants, or the Gram form of one tensor");
     AMPNET_REQUIRE(a.g.P2 && a.g.P3 && a.g.z, "pw_bwd_fused: BatchNorm constants incomplete");
@@ -540,6 +616,10 @@ int pw_bwd_fused(const PwBwd &a, hipStream_t st)
                    "pw_bwd_fused: per-window weights need workgroups that stay inside one window");
     AMPNET_REQUIRE(a.ldw % 4 == 0 && a.Q >= 1 && a.n_slots >= 1 && a.max_rows >= 1 && a.blocks_per_slot >= 1, "pw_bwd_fused: bad shape");
     AMPNET_REQUIRE(a.prev.C == 0 || pw_bwd_supported(a.g.C, a.prev.C), "pw_bwd_fused: %d x %d not built", a.g.C, a.prev.C);
+    AMPNET_REQUIRE(!a.fin_part_a || (a.fin_part_b && a.fin_parts >= a.n_slots && a.fin_rows >= 1 && a.fin_gamma && a.fin_mean && a.fin_invstd && a.fin_P1 && a.fin_P2 &&
+                                     a.fin_P3 && a.fin_slot_ab && !a.g.act && a.fin_part_a != a.part_a),
+                   "pw_bwd_fused: in-kernel BatchNorm-backward constants need the partials of the producer (not this launch's), the layer's statistics and outputs");
+    AMPNET_REQUIRE(!a.fin_part_a || !bwd_operands_bf16(), "pw_bwd_fused: in-kernel BatchNorm-backward constants are built for the fp32 kernel");
     if (bwd_operands_bf16()) return pw_bwd_fused_bf16(a, st);
     AMPNET_REQUIRE(!a.g.z_bf16 && !a.prev.z_bf16, "pw_bwd_fused: bf16 activation tensors need a bf16 precision mode");      // bf16 MFMA operands (pw_bwd_bf16.hip)
     if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);

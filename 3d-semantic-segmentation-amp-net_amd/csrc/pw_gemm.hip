@@ -78,6 +78,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     __bf16 *sWb = reinterpret_cast<__bf16 *>(smem);   // bf16: [CB][LDB]
     float *sPro = BF ? smem + CB * LDB / 2 : smem + CB * LDW;     // scale[CIN], shift[CIN]
     float *sRed = sPro + 2 * CIN;                                  // cross-wave reduction scratch (the weights stay resident)
+    double *sRun = reinterpret_cast<double *>(sRed + PW_NW * CB * 5 + PW_NW);   // [CB][2] per-workgroup running (mean, M2): a.part_rows mode
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,6 +96,21 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const int n_rb = a.Q * a.chunks;
     const int cb0 = (within / 8) * CB;
     const bool perwin_w = a.w_win_stride != 0;
+    // Statistics per WORKGROUP (a.part_rows != nullptr; every layer but the pooled ones): lane = (slot, j) = (lane_id % n_slots,
+    // lane_id / n_slots) walks the blocks of rows j, j + L_slot, ... of ITS slot only (L_slot = the lanes that slot has: stat_lanes / n_slots,
+    // one more for the first stat_lanes % n_slots slots), merges their (rows, mean, M2) as it goes and leaves ONE partial per column: ~57
+    // partials per slot for bn_finalize (one stage) instead of one per block of rows (two stages) -- or none at all when a slot is a single
+    // block of rows (the T-Net FC layers): then the BatchNorm constants are finished right here (fin_*).  With stat_lanes = the resident
+    // grid the blocks of rows are dealt exactly as evenly as by the slot-blind walk (2304 blocks over 512 lanes: 256 lanes take five, 256 four,
+    // and the five-block lanes are the low lane ids, so a CU's two workgroups -- ids c and c + 256 -- get nine between them).
+    const bool wg_stats = a.part_rows != nullptr;
+    const int stat_lanes = a.stat_lanes;
+    if (wg_stats && lane_id >= stat_lanes) return;                      // the grid is rounded up to the XCD pattern (whole workgroups leave)
+    const StatLane sl = wg_stats ? stat_lane_of(lane_id, stat_lanes, a.n_slots, a.Q, a.chunks) : StatLane{0, 0, 1};
+    const int my_slot = sl.slot, slot_lanes = sl.L;
+    const int part_idx = sl.slot + sl.j * a.n_slots;                    // where this lane's partial goes: slot = index % n_slots
+    const int slot_items = wg_stats ? ((a.Q - my_slot + a.n_slots - 1) / a.n_slots) * a.chunks : 0;
+    int run_n = 0;                                                      // rows merged so far (uniform)
 
     // ---- weight staging (transposing when the matrix is k-major) ----
     auto stage_weights = [&](int pidx) {
@@ -139,11 +155,12 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
     }
     int staged_slot = -1;
-  for (int rb = lane_id; rb < n_rb; rb += n_lanes) {
-    const int q = rb / a.chunks;
-    const int chunk = rb % a.chunks;
-    const int w_begin = a.win_off[q];
-    const int w_end = a.win_off[q + 1];
+  const int it_end = wg_stats ? slot_items : n_rb, it_step = wg_stats ? slot_lanes : n_lanes;
+  for (int it = wg_stats ? sl.j : lane_id; it < it_end; it += it_step) {
+    const int q = wg_stats ? my_slot + (it / a.chunks) * a.n_slots : it / a.chunks;
+    const int chunk = it % a.chunks;
+    const int w_begin = a.uniform_rows > 0 ? q * a.uniform_rows : a.win_off[q];
+    const int w_end = a.uniform_rows > 0 ? w_begin + a.uniform_rows : a.win_off[q + 1];
     const int row_begin = w_begin + chunk * a.chunk_rows;
     const int row_end = min(w_end, row_begin + a.chunk_rows);
     const int nrows = max(row_end - row_begin, 0);
@@ -187,6 +204,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
         bias_v[t] = (a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
+        // T-Net fc_3: the k x k output has the identity added (pointnetAtt.py:42-46): +1 on the columns i * (k + 1) of the k * k
+        if (a.identity_k > 0 && col < a.cout && col % (a.identity_k + 1) == 0) bias_v[t] += 1.0f;
         init_v[t] = bias_v[t];
     }
 
@@ -529,7 +548,18 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
         const float sg = (POOL && a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
-        if (do_stats) {
+        if (do_stats && wg_stats) {
+            // merge this block of rows into the workgroup's running partial (the same thread owns column c in every block)
+            if (run_n == 0) {
+                sRun[2 * c] = mean;
+                sRun[2 * c + 1] = m2 < 0.0 ? 0.0 : m2;
+            } else if (n > 0.0) {
+                const double rn = (double)run_n, rmean = sRun[2 * c], nn = rn + n;
+                const double delta = mean - rmean, wgt = n * rcp_f64(nn);
+                sRun[2 * c] = rmean + delta * wgt;
+                sRun[2 * c + 1] += (m2 < 0.0 ? 0.0 : m2) + delta * delta * rn * wgt;
+            }
+        } else if (do_stats) {
             a.part_sum[o] = sg * (float)mean;       // chunk mean (of z, not of the signed z')
             a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
@@ -538,7 +568,38 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             a.part_amax[o] = arg;
         }
     }
+    run_n += nrows;
   }   // blocks of rows
+    if (!(wg_stats && do_stats)) return;
+    // ---- the workgroup's partial (thread c wrote sRun[c] itself: no barrier needed), or the finished BatchNorm constants ----
+    for (int c = tid; c < CB; c += PW_NW * 64) {
+        const int col = cb0 + c;
+        if (col >= a.cout) continue;
+        const double mean = run_n > 0 ? sRun[2 * c] : 0.0, m2 = run_n > 0 ? sRun[2 * c + 1] : 0.0;
+        if (a.fin_scale) {                          // one lane per slot: this workgroup saw every row of its slot
+            const double N = (double)run_n;
+            const double var = N > 0.0 ? m2 / N : 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)a.fin_eps));
+            const size_t o = (size_t)my_slot * a.cout + col;
+            const float sc = a.fin_gamma[col] * invstd;
+            a.fin_scale[o] = sc;
+            a.fin_shift[o] = a.fin_beta[col] - (float)mean * sc;
+            if (a.fin_mean) a.fin_mean[o] = (float)mean;
+            if (a.fin_invstd) a.fin_invstd[o] = invstd;
+            if (a.fin_smean) {
+                a.fin_smean[o] = (float)mean;
+                a.fin_suvar[o] = (float)(N > 1.0 ? m2 / (N - 1.0) : m2);
+            }
+        } else {
+            a.part_sum[(size_t)part_idx * a.cout + col] = (float)mean;
+            a.part_sq[(size_t)part_idx * a.cout + col] = (float)m2;
+        }
+    }
+    if (tid == 0 && cb0 == 0 && !a.fin_scale) {
+        a.part_rows[part_idx] = run_n;
+        // slots with one lane fewer than the widest leave their last partial slot empty: mark it (rows 0) for bn_finalize
+        if (sl.j == sl.L - 1 && sl.L < (stat_lanes + a.n_slots - 1) / a.n_slots) a.part_rows[part_idx + a.n_slots] = 0;
+    }
 }
 
 template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
@@ -546,7 +607,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = BF ? (size_t)CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
-    constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float);
+    constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float) + (size_t)CB * 2 * sizeof(double);   // + sRun
     constexpr size_t lds = lds_main + lds_red;
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
     auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE>;
@@ -565,6 +626,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     int lanes = (resident / (8 * ncb)) * 8;
     if (lanes < 8) lanes = 8;
     if (lanes > cdiv(n_rb, 8) * 8) lanes = cdiv(n_rb, 8) * 8;
+    if (a.part_rows) lanes = cdiv(a.stat_lanes, 8) * 8;                // per-workgroup statistics: the plan fixes the lanes (pw_gemm_stat_plan)
     dim3 grid((unsigned)(lanes * ncb));
     char name[64];
     snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
@@ -610,9 +672,26 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
     return pro ? launch_pw_x<CIN, NT, 1, false>(a, st) : launch_pw_x<CIN, NT, 0, false>(a, st);
 }
 
+// lanes per slot for the per-workgroup statistics of a layer with one column block per row block: at most 512 workgroups (two per CU of
+// the MI355X; on another part the surplus queues, the result does not change), never more than a slot has blocks of rows
+PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots)
+{
+    PwStatPlan p;
+    const long items = (long)Q * chunks;                      // blocks of rows in all
+    int lanes = items < 512 ? (int)items : 512;
+    if (lanes < n_slots) lanes = n_slots;                     // every slot needs a lane (one that finds no rows writes an empty partial)
+    p.lanes = lanes;
+    p.parts = cdiv(lanes, n_slots) * n_slots;
+    p.direct = cdiv(Q, n_slots) * chunks == 1;                // every slot is ONE block of rows: the workgroup's statistics are the slot's
+    return p;
+}
+
 int pw_gemm(const PwGemm &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.A && a.W && a.win_off, "pw_gemm: null pointer");
+    AMPNET_REQUIRE(a.A && a.W && (a.win_off || a.uniform_rows > 0), "pw_gemm: null pointer");
+    AMPNET_REQUIRE(!a.part_rows || (a.part_sum && !a.part_max && a.stat_lanes >= a.n_slots && a.stat_lanes <= 2048), "pw_gemm: per-workgroup statistics need part_sum, no pool epilogue and a lane plan");
+    AMPNET_REQUIRE(!a.fin_scale || (a.part_rows && a.stat_lanes == a.n_slots && a.fin_gamma && a.fin_beta && a.fin_shift && cdiv(a.Q, a.n_slots) * a.chunks == 1),
+                   "pw_gemm: in-kernel BatchNorm constants need one block of rows per slot");
     AMPNET_REQUIRE(a.Q >= 1 && a.chunks >= 1 && a.cout >= 1, "pw_gemm: bad sizes Q=%d chunks=%d cout=%d", a.Q, a.chunks, a.cout);
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");

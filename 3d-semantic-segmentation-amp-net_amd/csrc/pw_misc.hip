@@ -20,58 +20,70 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
     __shared__ float red[4][64][3];
     __shared__ int red_n[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = blockIdx.y, chunk = blockIdx.x;
-    const int row_begin = a.win_off[q] + chunk * a.chunk_rows;
-    const int row_end = min(a.win_off[q + 1], row_begin + a.chunk_rows);
+    // Two grids.  part_rows == nullptr: block (chunk, q) handles one block of rows and writes its own statistics partial (eval mode: none).
+    // part_rows != nullptr (train): a 1-D grid of stat_lanes persistent blocks; block (slot, j) = (blockIdx.x % n_slots, / n_slots) walks
+    // the blocks of rows j, j + L_slot, ... of its slot and leaves ONE partial (like pw_gemm: bn_finalize then runs in one stage).
+    const bool wg = a.part_rows != nullptr;
+    const StatLane sl = wg ? stat_lane_of(blockIdx.x, a.stat_lanes, a.n_slots, a.Q, a.chunks) : StatLane{0, 0, 1};
+    const int my_slot = sl.slot, slot_lanes = sl.L;
+    const int part_idx = sl.slot + sl.j * a.n_slots;
+    const int items = wg ? ((a.Q - my_slot + a.n_slots - 1) / a.n_slots) * a.chunks : 1;
+    double run_mean = 0.0, run_m2 = 0.0;          // wave 0, lane = channel
+    int run_n = 0;
+    for (int it = wg ? sl.j : 0; it < items; it += slot_lanes) {
+        const int q = wg ? my_slot + (it / a.chunks) * a.n_slots : blockIdx.y, chunk = wg ? it % a.chunks : blockIdx.x;
+        const int row_begin = a.win_off[q] + chunk * a.chunk_rows;
+        const int row_end = min(a.win_off[q + 1], row_begin + a.chunk_rows);
 
-    // effective weights of this lane's output channel
-    float w[9];
-    if (a.mode == 0) {
+        // effective weights of this lane's output channel
+        float w[9];
+        if (a.mode == 0) {
 #pragma unroll
-        for (int f = 0; f < 9; ++f) w[f] = f < 3 ? a.W[lane * 3 + f] : 0.f;
-    } else {
-        const int pidx = a.perwin_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
-        const float *T = a.T + (size_t)pidx * 9;
+            for (int f = 0; f < 9; ++f) w[f] = f < 3 ? a.W[lane * 3 + f] : 0.f;
+        } else {
+            const int pidx = a.perwin_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+            const float *T = a.T + (size_t)pidx * 9;
 #pragma unroll
-        for (int f = 0; f < 9; ++f) {
-            float v = a.W[lane * 12 + 3 + f];
-            if (f < 3) v += T[f * 3 + 0] * a.W[lane * 12 + 0] + T[f * 3 + 1] * a.W[lane * 12 + 1] + T[f * 3 + 2] * a.W[lane * 12 + 2];
-            w[f] = v;
-        }
-    }
-    const int nf = a.mode == 0 ? 3 : 9;
-    float s = 0.f, sq = 0.f, z0 = 0.f;     // sums of (z - z0), (z - z0)^2 with z0 = the wave's first row (see pw_gemm.hip)
-    int cnt = 0;
-    for (int base = row_begin; base < row_end; base += IN_ROWS) {
-        const int n = min(IN_ROWS, row_end - base);
-        __syncthreads();
-        {
-            float tmp[9];
-#pragma unroll
-            for (int u = 0; u < 9; ++u) tmp[u] = (tid + 256 * u) < n * 9 ? a.x[(size_t)base * 9 + tid + 256 * u] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 9; ++u)
-                if ((tid + 256 * u) < n * 9) sx[tid + 256 * u] = tmp[u];
-        }
-        __syncthreads();
-        for (int i = wave; i < n; i += 4) {
-            float z = 0.f;
-            if (nf == 3) {
-                z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
-            } else {
-#pragma unroll
-                for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+            for (int f = 0; f < 9; ++f) {
+                float v = a.W[lane * 12 + 3 + f];
+                if (f < 3) v += T[f * 3 + 0] * a.W[lane * 12 + 0] + T[f * 3 + 1] * a.W[lane * 12 + 1] + T[f * 3 + 2] * a.W[lane * 12 + 2];
+                w[f] = v;
             }
-            if (a.z_bf16) reinterpret_cast<__bf16 *>(a.Z)[(size_t)(base + i) * 64 + lane] = (__bf16)z;
-            else a.Z[(size_t)(base + i) * 64 + lane] = z;
-            if (cnt == 0) z0 = z;
-            const float d = z - z0;
-            s += d;
-            sq = fmaf(d, d, sq);
-            ++cnt;
         }
-    }
-    if (a.part_sum) {
+        const int nf = a.mode == 0 ? 3 : 9;
+        float s = 0.f, sq = 0.f, z0 = 0.f;     // sums of (z - z0), (z - z0)^2 with z0 = the wave's first row (see pw_gemm.hip)
+        int cnt = 0;
+        for (int base = row_begin; base < row_end; base += IN_ROWS) {
+            const int n = min(IN_ROWS, row_end - base);
+            __syncthreads();
+            {
+                float tmp[9];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) tmp[u] = (tid + 256 * u) < n * 9 ? a.x[(size_t)base * 9 + tid + 256 * u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 9; ++u)
+                    if ((tid + 256 * u) < n * 9) sx[tid + 256 * u] = tmp[u];
+            }
+            __syncthreads();
+            for (int i = wave; i < n; i += 4) {
+                float z = 0.f;
+                if (nf == 3) {
+                    z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+                }
+                if (a.z_bf16) reinterpret_cast<__bf16 *>(a.Z)[(size_t)(base + i) * 64 + lane] = (__bf16)z;
+                else a.Z[(size_t)(base + i) * 64 + lane] = z;
+                if (cnt == 0) z0 = z;
+                const float d = z - z0;
+                s += d;
+                sq = fmaf(d, d, sq);
+                ++cnt;
+            }
+        }
+        if (!a.part_sum) continue;
+        __syncthreads();                           // the previous item's merge has read red[]
         red[wave][lane][0] = s;
         red[wave][lane][1] = sq;
         red[wave][lane][2] = z0;
@@ -79,21 +91,46 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
         __syncthreads();
         if (wave == 0) {
             double n = 0.0, mean = 0.0, m2 = 0.0;
-            for (int w = 0; w < 4; ++w) {
-                const double nw = (double)red_n[w];
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const double nw = (double)red_n[w2];
                 if (nw <= 0.0) continue;
-                const double s1 = red[w][lane][0], s2 = red[w][lane][1];
-                const double mw = (double)red[w][lane][2] + s1 / nw, m2w = s2 - s1 * s1 / nw;
+                const double s1 = red[w2][lane][0], s2 = red[w2][lane][1];
+                const double mw = (double)red[w2][lane][2] + s1 / nw, m2w = s2 - s1 * s1 / nw;
                 const double nn = n + nw, delta = mw - mean;
                 mean += delta * nw / nn;
                 m2 += m2w + delta * delta * n * nw / nn;
                 n = nn;
             }
-            const size_t o = (size_t)(q * a.chunks + chunk) * 64 + lane;
-            a.part_sum[o] = (float)mean;
-            a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);
+            if (m2 < 0.0) m2 = 0.0;
+            if (!wg) {
+                const size_t o = (size_t)(q * a.chunks + chunk) * 64 + lane;
+                a.part_sum[o] = (float)mean;
+                a.part_sq[o] = (float)m2;
+            } else if (n > 0.0) {                  // merge into the block's running partial (Chan)
+                const double rn = (double)run_n, nn = rn + n, delta = mean - run_mean;
+                run_mean += delta * n / nn;
+                run_m2 += m2 + delta * delta * rn * n / nn;
+                run_n += (int)n;
+            }
         }
     }
+    if (wg && a.part_sum && wave == 0) {
+        a.part_sum[(size_t)part_idx * 64 + lane] = (float)run_mean;
+        a.part_sq[(size_t)part_idx * 64 + lane] = (float)run_m2;
+        if (lane == 0) {
+            a.part_rows[part_idx] = run_n;
+            if (sl.j == sl.L - 1 && sl.L < (a.stat_lanes + a.n_slots - 1) / a.n_slots) a.part_rows[part_idx + a.n_slots] = 0;
+        }
+    }
+}
+
+// persistent blocks for pw_input's statistics: the kernel is HBM-bound and light on registers / LDS, so it wants several blocks per CU:
+// up to 1024 (four per CU), each walking the blocks of rows of one slot
+int pw_input_stat_lanes(int Q, int chunks, int n_slots)
+{
+    const long items = (long)Q * chunks;
+    int lanes = items < 1024 ? (int)items : 1024;
+    return lanes < n_slots ? n_slots : lanes;
 }
 
 int pw_input(const PwInput &a, hipStream_t st)
@@ -101,7 +138,9 @@ int pw_input(const PwInput &a, hipStream_t st)
     AMPNET_REQUIRE(a.x && a.W && a.Z && a.win_off, "pw_input: null pointer");
     AMPNET_REQUIRE(a.mode == 0 || a.T, "pw_input: mode 1 needs T");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_input: partials");
-    hipLaunchKernelGGL(pw_input_kernel, dim3(a.chunks, a.Q), dim3(256), 0, st, a);
+    AMPNET_REQUIRE(!a.part_rows || (a.part_sum && a.stat_lanes >= a.n_slots && a.n_slots >= 1), "pw_input: per-block statistics need part_sum and a plan");
+    if (a.part_rows) hipLaunchKernelGGL(pw_input_kernel, dim3(a.stat_lanes), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pw_input_kernel, dim3(a.chunks, a.Q), dim3(256), 0, st, a);
     return check_launch("pw_input_kernel");
 }
 
@@ -225,7 +264,7 @@ __global__ __launch_bounds__(64 * FIN_G) void bn_finalize_kernel(BnFinalize a, f
 
 int bn_finalize(const BnFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_sum && a.part_sq && (a.win_off || a.part_rows) && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
+    AMPNET_REQUIRE(a.part_sum && a.part_sq && (a.win_off || a.part_rows || a.uniform_rows > 0) && a.gamma && a.beta && a.scale && a.shift, "bn_finalize: null pointer");
     if (sync_bn_on()) {
         // global batch: merge the rank's partials per slot, all-gather the (rows, mean, M2) of every rank, finalize from those
         const size_t seg = (size_t)a.n_slots * (2 * (size_t)a.C + 1);
@@ -247,7 +286,7 @@ int bn_finalize(const BnFinalize &a, hipStream_t st)
         return check_launch("bn_finalize_kernel (global batch)");
     }
     const long per_slot_parts = (long)((a.Q + a.n_slots - 1) / a.n_slots) * a.chunks;
-    if (a.merge_ws && per_slot_parts >= 128 && a.n_slots * FIN_V <= a.Q) {
+    if (a.merge_ws && per_slot_parts > 192 && a.n_slots * FIN_V <= a.Q) {
         // few slots, thousands of partials each (the head: one slot): merge FIN_V sub-slots per slot on FIN_V x more
         // workgroups first, then finalize those
         const int V = a.n_slots * FIN_V;

@@ -261,6 +261,21 @@ def cls_head_backward(head_params, grad_table, gl, B, W, n_classes, drop_p, seed
     return d_gl
 
 
+def pad_mask(targets, W):
+    """targets [B, P] int64 GPU (cluster-major, -1 = padded) -> uint8 [B, W]: the reference's `(targets.view(B, -1, W) == -1).all(dim=1)`
+    (train_pointnet-attention.py:428-431) in one launch (include/ampnet_hip.h: ampnet_pad_mask_i64)."""
+    _lib.require_gpu(targets, "targets")
+    if targets.dtype != torch.int64 or targets.dim() != 2 or targets.shape[1] % W:
+        raise _lib.AmpnetError(f"pad_mask: targets must be int64 [B, P] with P % W == 0, got {tuple(targets.shape)} {targets.dtype}, W={W}")
+    t = targets.contiguous()
+    B, Pp = t.shape
+    mask = torch.empty((B, W), dtype=torch.uint8, device=t.device)
+    with torch.cuda.device(t.device):
+        rc = _lib.lib().ampnet_pad_mask_i64(_lib.ptr(t), B, Pp, W, _lib.ptr(mask), _lib.stream_ptr(t.device))
+    _lib.check(rc, "ampnet_pad_mask_i64")
+    return mask
+
+
 def reg_loss(feat_T, keep_G=False):
     """|| I - F F^T ||_F over the stack feat_T [n, 64, 64] -> device scalar tensor [1] (and G when keep_G)."""
     _lib.require_gpu(feat_T, "feat_T")

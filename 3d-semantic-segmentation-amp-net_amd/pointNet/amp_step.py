@@ -95,7 +95,8 @@ def forward_batch(pointnet, att_net, x, t, centroids, class_w=None, want_loss=Tr
     local, glob, feat_T = pointnet.forward_windows(xd.reshape(B * W, N, 9), n_slots=n_slots)
     # key_padding_mask exactly as the reference builds it (train_pointnet-attention.py:428-431): a view(B, -1, W)
     # of the cluster-concatenated targets, NOT a per-cluster test (SURVEY.md F-notes; restated literally).
-    mask = (tgd.view(B, -1, W) == -1).all(dim=1)
+    from .. import ops
+    mask = ops.pad_mask(tgd.long(), W)                    # == (tgd.view(B, -1, W) == -1).all(dim=1), one launch (ampnet_pad_mask_i64)
     logits, preds, loss = att_net.forward_rows(glob, local, cent, [N] * W, mask,
                                                targets=tgd if want_loss else None, class_w=class_w, want_preds=want_preds)
     # the reference's reg loss uses the transforms of the LAST encoder call = cluster slot W-1

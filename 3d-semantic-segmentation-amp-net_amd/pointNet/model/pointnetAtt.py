@@ -133,9 +133,12 @@ class BasePointNet(nn.Module):
     def _tables(self):
         return self._cache.get(self, P.ENC_PARAMS, P.ENC_BUFFERS, "BasePointNet")
 
+    def _bn_counters(self):
+        return [m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)]
+
     def _bump_batches(self, n):
         # one multi-tensor launch for the 16 counters (16 single-element kernels per step otherwise)
-        torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, _BN)], n)
+        torch._foreach_add_(self._bn_counters(), n)
 
     def forward_windows(self, x, np_cluster=None, n_slots=1):
         """All windows of a step in one launch sequence.

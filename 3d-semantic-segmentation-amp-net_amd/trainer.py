@@ -59,43 +59,66 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
 
+    def _advance(self, group):
+        """Bump the step counters of a group's parameters (state created on first use); returns (parameters with a gradient, step)."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        steps = set()
+        for p in ps:
+            _lib.require_gpu(p, "parameter")
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not torch.is_tensor(st["step"]):          # checkpoints written by torch < 1.12 keep Adam's step as a Python int
+                st["step"] = torch.tensor(float(st["step"]))
+            st["step"] += 1
+            steps.add(int(st["step"].item()))
+        if len(steps) > 1:
+            raise _lib.AmpnetError("FusedAdam: parameters of one group must share their step count")
+        return ps, (steps.pop() if steps else 0)
+
+    @staticmethod
+    def _launch(jobs, lr, b1, b2, eps, step, grad_scale):
+        """ONE multi-tensor launch over jobs = [(optimizer, parameters)]: they share every scalar of the update."""
+        ps = [p for _, plist in jobs for p in plist]
+        st = [o.state[p] for o, plist in jobs for p in plist]
+        n = len(ps)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
+        numel = (ctypes.c_long * n)(*[p.numel() for p in ps])
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+        dev = ps[0].device
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ampnet_adam_step_f32(arr(ps), arr(grads), arr([s["exp_avg"] for s in st]), arr([s["exp_avg_sq"] for s in st]), numel, n,
+                                                 ctypes.c_float(lr), ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(eps), step,
+                                                 ctypes.c_float(grad_scale), _lib.stream_ptr(dev))
+        _lib.check(rc, "ampnet_adam_step_f32")
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise _lib.AmpnetError("FusedAdam: closures are not supported")
-        L = _lib.lib()
         for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
-                continue
-            steps = set()
-            for p in ps:
-                _lib.require_gpu(p, "parameter")
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not torch.is_tensor(st["step"]):          # checkpoints written by torch < 1.12 keep Adam's step as a Python int
-                    st["step"] = torch.tensor(float(st["step"]))
-                st["step"] += 1
-                steps.add(int(st["step"].item()))
-            if len(steps) != 1:
-                raise _lib.AmpnetError("FusedAdam: parameters of one group must share their step count")
-            n = len(ps)
-            arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
-            numel = (ctypes.c_long * n)(*[p.numel() for p in ps])
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            dev = ps[0].device
-            b1, b2 = group["betas"]
-            with torch.cuda.device(dev):
-                rc = L.ampnet_adam_step_f32(arr(ps), arr(grads), arr([self.state[p]["exp_avg"] for p in ps]),
-                                            arr([self.state[p]["exp_avg_sq"] for p in ps]), numel, n,
-                                            ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
-                                            ctypes.c_float(group["eps"]), steps.pop(), ctypes.c_float(self.grad_scale),
-                                            _lib.stream_ptr(dev))
-            _lib.check(rc, "ampnet_adam_step_f32")
+            ps, step = self._advance(group)
+            if ps:
+                self._launch([(self, ps)], group["lr"], *group["betas"], group["eps"], step, self.grad_scale)
         return None
+
+    @staticmethod
+    @torch.no_grad()
+    def step_together(optimizers):
+        """optimizer.step() of several FusedAdam instances (the reference keeps one Adam per network, train_pointnet-attention.py:140-141) in
+        as few launches as their hyper-parameters allow: groups with the same (lr, betas, eps, step, grad_scale, device) share one
+        multi-tensor launch -- for the reference's recipe, one launch for both networks.  Same arithmetic, element by element."""
+        buckets = {}
+        for opt in optimizers:
+            for group in opt.param_groups:
+                ps, step = opt._advance(group)
+                if ps:
+                    key = (float(group["lr"]), tuple(float(b) for b in group["betas"]), float(group["eps"]), step, float(opt.grad_scale), ps[0].device)
+                    buckets.setdefault(key, []).append((opt, ps))
+        for (lr, (b1, b2), eps, step, gs, _), jobs in buckets.items():
+            FusedAdam._launch(jobs, lr, b1, b2, eps, step, gs)
 
 
 def _dist_world():
@@ -205,7 +228,6 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     off, total, mx = ops.window_offsets([N] * Q, dev)
     # ---- forward ----
     local, glob, feat_T, _ = ops.encoder_forward(ept, ebt, xr, off, Q, total, mx, W, True, pointnet._ws)
-    pointnet._bump_batches(W)
     gru = getattr(att_net, "head_kind", "attention") == "gru"      # SegmentationWithGRU: no centroids, no key-padding mask
     seed = (att_net.seed + 0x632BE5AB * att_net._step) & 0xFFFFFFFF
     att_net._step += 1
@@ -215,10 +237,12 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
         logits, preds, loss2 = ops.gru_head_forward(hpt, hbt, glob, local, off, B, W, total, mx, att_net.num_classes, True, att_net.p_drop,
                                                     seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
     else:
-        mask = (tgd.view(B, -1, W) == -1).all(dim=1)                # the reference's literal mask (amp_step.forward_batch)
+        mask = ops.pad_mask(tgd, W)                                 # the reference's literal (targets.view(B, -1, W) == -1).all(dim=1), one launch
         logits, preds, loss2 = ops.head_forward(hpt, hbt, glob, local, cent, off, mask, B, W, total, mx, att_net.num_classes, True,
                                                 att_net.p_drop, seed, att_net._ws, targets=tgd, class_w=class_w, want_preds=True)
-    torch._foreach_add_([att_net.bn_2.num_batches_tracked, att_net.bn_3.num_batches_tracked], 1)
+    # num_batches_tracked: + W for the encoder's 16 BatchNorms (W encoder calls in the reference), + 1 for the head's two; one launch
+    counters = pointnet._bn_counters() + [att_net.bn_2.num_batches_tracked, att_net.bn_3.num_batches_tracked]
+    torch._foreach_add_(counters, [W] * (len(counters) - 2) + [1, 1])
     feat_last = feat_T[-B:]
     reg, G = ops.reg_loss(feat_last, keep_G=True)
     # ---- backward ----
@@ -290,8 +314,11 @@ def shard_indices(n_samples, rank, world, drop_last=True):
 def fused_train_step(pointnet, att_net, optimizer_pointnet, optimizer_att, x, t, centroids, class_w):
     out = forward_backward(pointnet, att_net, x, t, centroids, class_w, overlap_allreduce=True)
     reduce_gradients(out["grad_bufs"], (optimizer_pointnet, optimizer_att), out["pending"])
-    optimizer_pointnet.step()
-    optimizer_att.step()
+    if isinstance(optimizer_pointnet, FusedAdam) and isinstance(optimizer_att, FusedAdam):
+        FusedAdam.step_together((optimizer_pointnet, optimizer_att))          # one multi-tensor launch for both networks
+    else:
+        optimizer_pointnet.step()
+        optimizer_att.step()
     return out
 
 

@@ -238,6 +238,10 @@ int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float
  * what rm_padding removes, utils/utils.py:14-19); counts is WRITTEN ([C * C + 1] int64).  accuracy = trace / kept; IoU of label c =
  * counts[c][c] / (row sum c + column sum c - counts[c][c]).  Lets a training driver keep predictions on the device: no 2 x 9.4 MB
  * download and no synchronisation per step.                                                                                      */
+/* the key-padding mask of train_loop (train_pointnet-attention.py:428-431): targets [B, P] int64 (cluster-major, -1 = padded point),
+ * mask[b, w] = 1 iff targets[b, i * W + w] == -1 for every i -- the reference's literal `(targets_pc.view(B, -1, W) == -1).all(dim=1)`.
+ * W <= 32, P % W == 0.  One launch instead of five torch launches per step.                                                         */
+int ampnet_pad_mask_i64(const long long *targets, int B, int P, int W, uint8_t *mask, void *stream);
 int ampnet_confusion_i64(const long long *preds, const long long *targets, long long n, int n_classes, long long *counts, void *stream);
 
 /* ---- a8 on the device: the input pipeline of train_loop in one kernel --------------------------------------------

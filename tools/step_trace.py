@@ -22,7 +22,8 @@ def short(n):
 
 
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-ends = adam[1::2]                                  # second adam launch of every step
+# the last adam launch of every step: one launch per step (FusedAdam.step_together) or two back to back (one per optimiser)
+ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 4]
 lo, hi = ends[-1 - back] + 1, ends[-back] + 1
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"])
