@@ -5,6 +5,8 @@
 namespace ampnet {
 
 int fc_act(const float *z, const float *s, const float *t, int rows, int C, int per, float *act, hipStream_t st);
+int fc_act_pair(const float *z0, const float *s0, const float *t0, int C0, float *a0, const float *z1, const float *s1, const float *t1, int C1, float *a1,
+                int rows, int per, hipStream_t st);
 int fc_bn_bwd(const float *da, const float *z, const float *scale, const float *shift, const float *mean, const float *invstd,
               int n_slots, int per, int C, float *g, float *slot_ab, hipStream_t st);
 int colsum(const float *x, int rows, int C, float *out, hipStream_t st);

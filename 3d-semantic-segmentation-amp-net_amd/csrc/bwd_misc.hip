@@ -208,15 +208,15 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 // of 256 threads each walk a quarter of K with their own LDS tiles and the partial 32 x 32 tiles are summed through LDS in a
 // fixed order -- a quarter of the dependent (load -> barrier -> multiply) trips per launch.
 constexpr int SG_SK = 4;
+constexpr int SG_KD = 64;               // depth of a k slice per group and trip: K = 576 is three trips of 4 x 64 (five of 4 x 32 before: the
+                                       // launches are bound by those dependent load -> barrier -> multiply trips, ~2.5 us each)
 
 struct SgProblem {
     int M, N, K, ta, tb, lda, ldb, ldc, accumulate;
     const float *A, *B;
     float *C;
-    // B(k, n) = relu(B(k, n) * bs[k / bper][n] + bt[k / bper][n]) while loaded (tb == 0): the T-Net FC activations are never materialised
-    const float *bs = nullptr, *bt = nullptr;
-    int bper = 1;
-    int b_ones = 0;                    // B is all ones (row sums of op(A): a bias gradient G^T 1 as one more problem of the launch, N = 1)
+    float *db = nullptr;               // [M]: row sums of op(A) over K (the bias gradient G^T 1 of a weight-gradient problem), taken by the
+                                       // workgroups of the first column of tiles from the A tile they stage anyway: no extra problem, no extra launch
 };
 constexpr int SG_MAX_PROBLEMS = 10;
 struct SgArgs {
@@ -225,7 +225,7 @@ struct SgArgs {
 
 __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
 {
-    __shared__ float sA[SG_SK][32][33], sB[SG_SK][32][33];     // [group][k][m], [group][k][n]
+    __shared__ float sA[SG_SK][SG_KD][33], sB[SG_SK][SG_KD][33];     // [group][k][m], [group][k][n]
     const SgProblem &g = args.p[blockIdx.z];
     const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb;
     const bool TA = g.ta != 0, TB = g.tb != 0;
@@ -233,51 +233,53 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
     const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     if (m0 >= M || n0 >= N) return;                             // the grid covers the larger of the two problems (uniform per block)
-    // group g owns the k tiles g, g + SK, ... (32 deep each)
+    // group g owns the k tiles g, g + SK, ... (SG_KD deep each)
     float acc[2][2] = {};
-    float ra[4], rb[4];
+    float rs0 = 0.f, rs1 = 0.f;                                 // row sums of op(A) (g.db): rows ty and ty + 16 of the tile, threads tx == 0 of tile column 0
+    const bool do_rs = g.db != nullptr && blockIdx.x == 0 && tx == 0;
+    constexpr int NF = SG_KD * 32 / 256;                        // elements of each operand a thread stages per trip
+    float ra[NF], rb[NF];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NF; ++i) {
             const int e = tid + 256 * i;
-            const int m = TA ? e % 32 : e / 32, k = TA ? e / 32 : e % 32;
+            const int m = TA ? e % 32 : e / SG_KD, k = TA ? e / 32 : e % SG_KD;
             const int gm = m0 + m, gk = k0 + k;
             ra[i] = (gm < M && gk < K) ? (TA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.f;
-            const int n = TB ? e / 32 : e % 32, k2 = TB ? e % 32 : e / 32;
+            const int n = TB ? e / SG_KD : e % 32, k2 = TB ? e % SG_KD : e / 32;
             const int gn = n0 + n, gk2 = k0 + k2;
-            float bv = (gn < N && gk2 < K) ? (g.b_ones ? 1.0f : (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn])) : 0.f;
-            if (g.bs && gn < N && gk2 < K) {
-                const size_t so = (size_t)(gk2 / g.bper) * N + gn;
-                bv = fmaxf(fmaf(bv, g.bs[so], g.bt[so]), 0.f);
-            }
-            rb[i] = bv;
+            rb[i] = (gn < N && gk2 < K) ? (TB ? B[(size_t)gn * ldb + gk2] : B[(size_t)gk2 * ldb + gn]) : 0.f;
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NF; ++i) {
             const int e = tid + 256 * i;
-            if (TA) sA[grp][e / 32][e % 32] = ra[i]; else sA[grp][e % 32][e / 32] = ra[i];
-            if (TB) sB[grp][e % 32][e / 32] = rb[i]; else sB[grp][e / 32][e % 32] = rb[i];
+            if (TA) sA[grp][e / 32][e % 32] = ra[i]; else sA[grp][e % SG_KD][e / SG_KD] = ra[i];
+            if (TB) sB[grp][e % SG_KD][e / SG_KD] = rb[i]; else sB[grp][e / 32][e % 32] = rb[i];
         }
     };
-    const int ktiles = (K + 31) / 32;
+    const int ktiles = (K + SG_KD - 1) / SG_KD;
     const int trips = (ktiles + SG_SK - 1) / SG_SK;            // the same for every group (the barriers are workgroup-wide)
-    fetch(32 * grp);
+    fetch(SG_KD * grp);
     for (int i = 0; i < trips; ++i) {
         const int kt = grp + i * SG_SK;
         __syncthreads();
         stash();
         __syncthreads();
-        if (i + 1 < trips) fetch(32 * (kt + SG_SK));           // tiles past K load zeros
+        if (i + 1 < trips) fetch(SG_KD * (kt + SG_SK));        // tiles past K load zeros
         if (kt < ktiles) {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
+            for (int k = 0; k < SG_KD; ++k) {
                 const float a0 = sA[grp][k][ty], a1 = sA[grp][k][ty + 16], b0 = sB[grp][k][tx], b1 = sB[grp][k][tx + 16];
                 acc[0][0] = fmaf(a0, b0, acc[0][0]);
                 acc[0][1] = fmaf(a0, b1, acc[0][1]);
                 acc[1][0] = fmaf(a1, b0, acc[1][0]);
                 acc[1][1] = fmaf(a1, b1, acc[1][1]);
+                if (do_rs) {
+                    rs0 += a0;
+                    rs1 += a1;
+                }
             }
         }
     }
@@ -289,6 +291,21 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
 #pragma unroll
         for (int j = 0; j < 2; ++j) red[(grp * 4 + i * 2 + j) * 256 + tid] = acc[i][j];
     __syncthreads();
+    if (g.db && blockIdx.x == 0) {                              // uniform per block: the SK groups' row sums, group order
+        __syncthreads();
+        float *rsum = &sB[0][0][0];                             // [SK][32]
+        if (tx == 0) {
+            rsum[grp * 32 + ty] = rs0;
+            rsum[grp * 32 + ty + 16] = rs1;
+        }
+        __syncthreads();
+        if (grp == 0 && tid < 32 && m0 + tid < M) {
+            float v = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < SG_SK; ++g2) v += rsum[g2 * 32 + tid];
+            g.db[m0 + tid] = v;
+        }
+    }
     if (grp != 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -315,8 +332,7 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < n; ++i) {
         const SgProblem &p = probs[i];
-        AMPNET_REQUIRE(p.A && (p.B || p.b_ones) && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "sgemm_small: bad arguments");
-        AMPNET_REQUIRE(!p.bs || (p.bt && p.tb == 0 && p.bper >= 1), "sgemm_small: the fused activation is built for a row-major B");
+        AMPNET_REQUIRE(p.A && p.B && p.C && p.M >= 1 && p.N >= 1 && p.K >= 1, "sgemm_small: bad arguments");
         a.p[i] = p;
         gx = cdiv(p.N, 32) > gx ? cdiv(p.N, 32) : gx;
         gy = cdiv(p.M, 32) > gy ? cdiv(p.M, 32) : gy;
@@ -339,29 +355,21 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
 // weight gradient + bias gradient of the LAST layer of a chain (no data gradient wanted): dW [n_out, n_in] = G^T X, db [n_out] = column sums of G
 int sgemm_wgrad_bias(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, float *dW, int lddw, float *db, hipStream_t st)
 {
-    SgProblem p[2];
-    p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
-    p[1] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, db};      // db [n_out, 1] = G^T 1: the grid shape of the dW problem
-    p[1].b_ones = 1;
-    return sgemm_launch(p, db ? 2 : 1, st);
+    SgProblem p = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
+    p.db = db;
+    return sgemm_launch(&p, 1, st);
 }
 
 // the weight gradient dW = G^T X ([N_out, N_in] = [rows, N_out]^T [rows, N_in]) and the data gradient dX = G W of one linear layer
-// on [rows, *] activations, one launch (the two products are independent)
+// on [rows, *] activations, one launch (the two products are independent); o.db: the bias gradient rides in the dW problem
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
                      float *dX, int lddx, hipStream_t st, const LinBwdOpt &o)
 {
-    SgProblem p[3];
+    SgProblem p[2];
     p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
-    p[0].bs = o.xs; p[0].bt = o.xt; p[0].bper = o.x_per > 0 ? o.x_per : 1;
+    p[0].db = o.db;
     p[1] = {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX};
-    int n = 2;
-    if (o.db) {                                  // the bias gradient: ones^T G, one more problem of the same launch
-        p[2] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, o.db};
-        p[2].b_ones = 1;
-        n = 3;
-    }
-    return sgemm_launch(p, n, st);
+    return sgemm_launch(p, 2, st);
 }
 
 // the same for a layer with thousands of outputs (the feature T-Net's fc_3: 128 -> 4096): dX = G W has few output tiles and a K of n_out, so
@@ -370,19 +378,14 @@ int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, con
 int sgemm_linear_bwd_ksplit(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW,
                             int lddw, float *dX, int lddx, float *scratch, int splits, hipStream_t st, const LinBwdOpt &o)
 {
-    AMPNET_REQUIRE(scratch && splits >= 2 && splits + 2 <= SG_MAX_PROBLEMS && n_out % splits == 0, "sgemm_linear_bwd_ksplit: %d outputs in %d splits", n_out, splits);
+    AMPNET_REQUIRE(scratch && splits >= 2 && splits < SG_MAX_PROBLEMS && n_out % splits == 0, "sgemm_linear_bwd_ksplit: %d outputs in %d splits", n_out, splits);
     SgProblem p[SG_MAX_PROBLEMS];
     p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
-    p[0].bs = o.xs; p[0].bt = o.xt; p[0].bper = o.x_per > 0 ? o.x_per : 1;
+    p[0].db = o.db;
     const int kc = n_out / splits;
     for (int c = 0; c < splits; ++c)
         p[1 + c] = {rows, n_in, kc, 0, 0, ldg, ldw, n_in, 0, G + (size_t)c * kc, W + (size_t)c * kc * ldw, scratch + (size_t)c * rows * n_in};
-    int np = 1 + splits;
-    if (o.db) {
-        p[np] = {n_out, 1, rows, 1, 0, ldg, 1, 1, 0, G, nullptr, o.db};
-        p[np].b_ones = 1;
-        ++np;
-    }
+    const int np = 1 + splits;
     int rc = sgemm_launch(p, np, st);
     if (rc != AMPNET_OK) return rc;
     return reduce_windows(scratch, splits, (long)rows * n_in, rows, n_in, n_in, dX, lddx, 0, st);
@@ -399,6 +402,32 @@ __global__ void fc_act_kernel(const float *__restrict__ z, const float *__restri
     const int row = (int)(i / C), c = (int)(i % C);
     const size_t so = (size_t)(row / per) * C + c;
     act[i] = fmaxf(fmaf(z[i], s[so], t[so]), 0.f);
+}
+
+// two activations (the T-Net's a1 [rows, C0] and a2 [rows, C1]) in one launch
+__global__ void fc_act_pair_kernel(const float *__restrict__ z0, const float *__restrict__ s0, const float *__restrict__ t0, int C0, float *__restrict__ a0,
+                                   const float *__restrict__ z1, const float *__restrict__ s1, const float *__restrict__ t1, int C1, float *__restrict__ a1,
+                                   int rows, int per)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, n0 = (size_t)rows * C0, n1 = (size_t)rows * C1;
+    if (i < n0) {
+        const int row = (int)(i / C0), c = (int)(i % C0);
+        const size_t so = (size_t)(row / per) * C0 + c;
+        a0[i] = fmaxf(fmaf(z0[i], s0[so], t0[so]), 0.f);
+    } else if (i < n0 + n1) {
+        const size_t k = i - n0;
+        const int row = (int)(k / C1), c = (int)(k % C1);
+        const size_t so = (size_t)(row / per) * C1 + c;
+        a1[k] = fmaxf(fmaf(z1[k], s1[so], t1[so]), 0.f);
+    }
+}
+
+int fc_act_pair(const float *z0, const float *s0, const float *t0, int C0, float *a0, const float *z1, const float *s1, const float *t1, int C1, float *a1,
+                int rows, int per, hipStream_t st)
+{
+    const size_t n = (size_t)rows * (C0 + C1);
+    hipLaunchKernelGGL(fc_act_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z0, s0, t0, C0, a0, z1, s1, t1, C1, a1, rows, per);
+    return check_launch("fc_act_pair_kernel");
 }
 
 int fc_act(const float *z, const float *s, const float *t, int rows, int C, int per, float *act, hipStream_t st)
@@ -519,7 +548,7 @@ int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
 // ----------------------------------------------------------------------------------------------------
 // input layers (K = 3 / 9): per-window dWeff[q][c][f] = sum_rows g[row][c] * x[row][f], lane = channel c
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
+template <bool ZB> __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
 {
     __shared__ float sx[256 * 9];
     __shared__ float red[4][64][9];
@@ -543,7 +572,7 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
                 const int i = min(i0 + 4 * u, n - 1);
                 const size_t o = (size_t)(base + i) * 64 + lane;
                 dyv[u] = a.dy[o];
-                zv[u] = ld_act(a.z, o, a.z_bf16);
+                zv[u] = ld_act_t<ZB>(a.z, o);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -569,7 +598,8 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
 int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.x && a.dy && a.z && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
-    hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(256), 0, st, a);
+    if (a.z_bf16) hipLaunchKernelGGL(pw_input_wgrad_kernel<true>, dim3(a.Q), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pw_input_wgrad_kernel<false>, dim3(a.Q), dim3(256), 0, st, a);
     return check_launch("pw_input_wgrad_kernel");
 }
 
@@ -868,7 +898,7 @@ int sparse_fix(const SparseFix &a, hipStream_t st)
 //   out[row][k] += mask(row, k) * sum_chain P1[c] dpm[c] W[c][k]
 // together with that window's share of the BatchNorm-backward sums.  Eight rows per trip, all loads before the first use.
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void sparse_scatter_kernel(SparseScatter a)
+template <bool ZB> __global__ __launch_bounds__(512) void sparse_scatter_kernel(SparseScatter a)
 {
     __shared__ int sArg[256], sOwn[256], sNext[256];
     __shared__ float sCoef[256];
@@ -923,7 +953,7 @@ __global__ __launch_bounds__(512) void sparse_scatter_kernel(SparseScatter a)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 wv8[u] = a.W[(size_t)ch[u] * a.cp + k];
-                zv[u] = ld_act(a.z_prev, (size_t)rowv[u] * a.cp + k, a.z_bf16);
+                zv[u] = ld_act_t<ZB>(a.z_prev, (size_t)rowv[u] * a.cp + k);
                 ov[u] = a.out[(size_t)rowv[u] * a.cp + k];
             }
 #pragma unroll
@@ -953,7 +983,8 @@ int sparse_scatter(const SparseScatter &a, hipStream_t st)
     AMPNET_REQUIRE(a.arg && a.dpm && a.P1 && a.W && a.z_prev && a.s_prev && a.t_prev && a.mean_prev && a.invstd_prev && a.out && a.part_a && a.part_b,
                    "sparse_scatter: null pointer");
     AMPNET_REQUIRE(a.cp <= 128 && a.C <= 256, "sparse_scatter: C=%d cp=%d", a.C, a.cp);
-    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(a.Q), dim3(512), 0, st, a);
+    if (a.z_bf16) hipLaunchKernelGGL(sparse_scatter_kernel<true>, dim3(a.Q), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(sparse_scatter_kernel<false>, dim3(a.Q), dim3(512), 0, st, a);
     return check_launch("sparse_scatter_kernel");
 }
 
@@ -1060,7 +1091,7 @@ int reduce_slots2(const float *part0, int n_el0, float *out0, const float *part1
 // block = output channel c, thread = input channel k
 constexpr int PWG_G = 4;       // thread groups per output channel: 4 x more gathers in flight than one group
 
-__global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a)
+template <bool ZB> __global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a)
 {
     __shared__ float sW[256];
     __shared__ float sRed[PWG_G][128];
@@ -1098,7 +1129,7 @@ __global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a
 #pragma unroll 8
         for (int q = grp; q < a.Q; q += PWG_G) {
             const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
-            const float av = fmaxf(fmaf(ld_act(zp, (size_t)sRow[q] * a.cp + k, a.z_bf16), sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
+            const float av = fmaxf(fmaf(ld_act_t<ZB>(zp, (size_t)sRow[q] * a.cp + k), sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
             acc = fmaf(sCoef[q], av, acc);
         }
     }
@@ -1112,7 +1143,8 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
     AMPNET_REQUIRE(a.W && a.P1 && a.P2 && a.P3 && a.gram && a.asum && a.arg && a.dpm && a.z_prev && a.s_prev && a.t_prev && a.dW, "pooled_wgrad: null pointer");
     const size_t lds = ((size_t)a.Q * 2 + (size_t)a.n_slots * a.cp * 2) * sizeof(int);
     AMPNET_REQUIRE(a.cp <= 128 && lds <= 60 * 1024, "pooled_wgrad: cp=%d Q=%d n_slots=%d", a.cp, a.Q, a.n_slots);
-    hipLaunchKernelGGL(pooled_wgrad_kernel, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
+    if (a.z_bf16) hipLaunchKernelGGL(pooled_wgrad_kernel<true>, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
+    else hipLaunchKernelGGL(pooled_wgrad_kernel<false>, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
     return check_launch("pooled_wgrad_kernel");
 }
 

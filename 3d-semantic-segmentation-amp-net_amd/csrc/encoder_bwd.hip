@@ -362,20 +362,20 @@ struct EncBwd {
     int tnet_fc_bwd(int pbase, int bn0, const float *g3, int kk, const float *pooled, const float *zf1, const float *zf2) const
     {
         const int Q = s.Q, per = s.fc_rows, ns = s.n_slots;
-        // the activations a1 = relu(bn_4(zf1)), a2 = relu(bn_5(zf2)) are rebuilt while the weight-gradient GEMMs load them (LinBwdOpt.xs / xt);
-        // fc_3's bias gradient rides in the same launch as its two GEMMs
-        LinBwdOpt o3, o2;
-        o3.xs = f.bn[bn0 + 4].scale; o3.xt = f.bn[bn0 + 4].shift; o3.x_per = per; o3.db = G[pbase + TP_FC3_B];
-        o2.xs = f.bn[bn0 + 3].scale; o2.xt = f.bn[bn0 + 3].shift; o2.x_per = per;
+        // the activations a1 = relu(bn_4(zf1)), a2 = relu(bn_5(zf2)) in ONE launch (fusing them into the GEMMs' operand loads was measured:
+        // + 8 .. 50 us per launch, the loads of a latency-bound kernel tripled); fc_3's bias gradient rides inside its weight-gradient problem
+        TRY(fc_act_pair(zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, 256, b.a1, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, 128, b.a2, Q, per, st));
+        LinBwdOpt o3;
+        o3.db = G[pbase + TP_FC3_B];
         // fc_3: z3 = a2 W3^T + b3
         if (kk >= 1024)
-            TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, zf2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st, o3));
+            TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st, o3));
         else
-            TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, zf2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st, o3));
+            TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st, o3));
         TRY(fc_bn_bwd(b.da2, zf2, f.bn[bn0 + 4].scale, f.bn[bn0 + 4].shift, f.bn[bn0 + 4].mean, f.bn[bn0 + 4].invstd, ns, per, 128, b.g2,
                       b.bn[bn0 + 4].slot_ab, st));
         // fc_2
-        TRY(sgemm_linear_bwd(Q, 128, 256, b.g2, 128, zf1, 256, P[pbase + TP_FC2], 256, G[pbase + TP_FC2], 256, b.da1, 256, st, o2));
+        TRY(sgemm_linear_bwd(Q, 128, 256, b.g2, 128, b.a1, 256, P[pbase + TP_FC2], 256, G[pbase + TP_FC2], 256, b.da1, 256, st));
         TRY(fc_bn_bwd(b.da1, zf1, f.bn[bn0 + 3].scale, f.bn[bn0 + 3].shift, f.bn[bn0 + 3].mean, f.bn[bn0 + 3].invstd, ns, per, 256, b.g1,
                       b.bn[bn0 + 3].slot_ab, st));
         // fc_1 on the pooled features

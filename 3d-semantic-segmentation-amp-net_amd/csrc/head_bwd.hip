@@ -31,7 +31,7 @@ struct HeadOutBwd {
 // Per row the lane loads z3[row][k] (one 256-byte line per wave), rebuilds a3 = dropout(relu(bn_3(z3))), forms
 // da3[k] = sum_c dlogits[row][c] W4[c][k] from five wave-uniform gradients (loaded 64 rows at a time with lane = row and
 // broadcast by readlane), masks it and accumulates dW4[c][k], sum dy3, sum dy3 * zhat in registers.
-__global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd a)
+template <bool ZB> __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd a)
 {
     __shared__ float red[HB_WAVES][HEAD_MAX_CLASSES + 3][64];
     const int tid = threadIdx.x, k = tid & 63, wave = tid >> 6;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd 
         // the next eight rows are requested before the current eight are processed (register double buffer)
         float zn[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) zn[u] = ld_act(a.z3, (size_t)min(r0 + u, a.R - 1) * 64 + k, a.z_bf16);
+        for (int u = 0; u < 8; ++u) zn[u] = ld_act_t<ZB>(a.z3, (size_t)min(r0 + u, a.R - 1) * 64 + k);
 #pragma unroll 1
         for (int i0 = 0; i0 < 64; i0 += 8) {
             if (r0 + i0 >= a.R) break;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * HB_WAVES) void head_out_bwd_kernel(HeadOutBwd 
             for (int u = 0; u < 8; ++u) zv[u] = zn[u];
             if (i0 + 8 < 64) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) zn[u] = ld_act(a.z3, (size_t)min(r0 + i0 + 8 + u, a.R - 1) * 64 + k, a.z_bf16);
+                for (int u = 0; u < 8; ++u) zn[u] = ld_act_t<ZB>(a.z3, (size_t)min(r0 + i0 + 8 + u, a.R - 1) * 64 + k);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -298,7 +298,8 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
         o.W = p_.conv4_w; o.drop_p = drop_p; o.drop_seed = drop_base(seed, 2);
         o.R = R; o.P = R / B; o.C = C;
         o.dy3 = b.dy3; o.part_a = b.part_a; o.part_b = b.part_b; o.dWpart = b.w4part;
-        hipLaunchKernelGGL(head_out_bwd_kernel, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
+        if (o.z_bf16) hipLaunchKernelGGL(head_out_bwd_kernel<true>, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
+        else hipLaunchKernelGGL(head_out_bwd_kernel<false>, dim3(blocks), dim3(64 * HB_WAVES), 0, st, o);
         TRY(check_launch("head_out_bwd_kernel"));
         red[n_red++] = ReduceItem{b.w4part, blocks, (long)(C * 64 + C), 1, C * 64, C * 64, g.conv4_w, C * 64};
         red[n_red++] = ReduceItem{b.w4part + C * 64, blocks, (long)(C * 64 + C), 1, C, C, g.conv4_b, C};

@@ -89,6 +89,13 @@ __device__ __forceinline__ float ld_act(const float *base, size_t elem, int bf16
 {
     return bf16 ? (float)reinterpret_cast<const __bf16 *>(base)[elem] : base[elem];
 }
+// the same with the format fixed at compile time: a runtime flag puts a branch around every load, and the gather loops of the backward
+// (eight or sixteen independent loads per trip) then wait for each one in turn -- measured 2.2 x on pw_input_wgrad in mode 3
+template <bool ZB> __device__ __forceinline__ float ld_act_t(const float *base, size_t elem)
+{
+    if constexpr (ZB) return (float)reinterpret_cast<const __bf16 *>(base)[elem];
+    else return base[elem];
+}
 // activations kept for the backward (the nine pre-BatchNorm z tensors of the encoder, z2 / z3 of the head) are stored as bf16
 inline bool z_storage_bf16() { return matrix_precision() == AMPNET_PRECISION_BF16_STORE; }
 // bf16 MFMA operands in the fused backward (modes 2 and 3)
@@ -434,9 +441,7 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
                 int accumulate, hipStream_t st);
 // backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W
 struct LinBwdOpt {
-    float *db = nullptr;                         // [n_out]: the bias gradient (column sums of G) as one more problem of the same launch
-    const float *xs = nullptr, *xt = nullptr;    // [rows / x_per, n_in]: X = relu(X * xs + xt) while loaded (the T-Net FC activations: never materialised)
-    int x_per = 0;
+    float *db = nullptr;                         // [n_out]: the bias gradient (column sums of G), taken inside the weight-gradient problem
 };
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
                      float *dX, int lddx, hipStream_t st, const LinBwdOpt &o = LinBwdOpt());

@@ -159,74 +159,38 @@ extern "C" int ampnet_confusion_i64(const long long *preds, const long long *tar
 // (a view(B, -1, W) of cluster-major data, restated literally: SURVEY F-notes).  As torch ops on the GPU that is a compare, two fills, a
 // strided reduction and a copy: five launches, 46 us per step for 9 MB; here one workgroup per sample reads its row once.
 namespace ampnet {
-// grid (segments, B): block (g, b) scans a contiguous share of sample b's row with eight loads in flight per thread and ORs its "column w has a
-// real point" bits into seen[b] (integer OR: order-independent, exact); the last block of a sample to arrive (integer ticket) turns the bits into
-// the mask and resets both words, so the scratch is zero again for the next call.  seen / ticket: [B] uint32, zero before the first call.
-__global__ __launch_bounds__(256) void pad_mask_kernel(const long long *__restrict__ targets, int P, int W, uint8_t *__restrict__ mask,
-                                                       unsigned int *__restrict__ seen_ws, unsigned int *__restrict__ ticket_ws)
+// one workgroup of 1024 threads per sample: its row is read once, up to eight loads in flight per thread
+__global__ __launch_bounds__(1024) void pad_mask_kernel(const long long *__restrict__ targets, int P, int W, uint8_t *__restrict__ mask)
 {
-    __shared__ unsigned int s_seen[4];
-    __shared__ unsigned int s_last;
-    const int b = blockIdx.y, tid = threadIdx.x, segs = gridDim.x;
+    __shared__ unsigned int s_seen[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const long long *row = targets + (size_t)b * P;
-    const int per = (P + segs - 1) / segs, e0 = blockIdx.x * per, e1 = min(P, e0 + per);
     unsigned int seen = 0u;                                   // bit w: some element of column w is not -1
-    for (int base = e0 + tid; base < e1; base += 256 * 8) {
+    for (int base = tid; base < P; base += 1024 * 8) {
         long long v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = base + 256 * u < e1 ? row[base + 256 * u] : -1;
+        for (int u = 0; u < 8; ++u) v[u] = base + 1024 * u < P ? row[base + 1024 * u] : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (v[u] != -1) seen |= 1u << ((base + 256 * u) % W);
+            if (v[u] != -1) seen |= 1u << ((base + 1024 * u) % W);
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) seen |= __shfl_xor(seen, o);
     if ((tid & 63) == 0) s_seen[tid >> 6] = seen;
     __syncthreads();
-    if (tid == 0) {
-        const unsigned int all = s_seen[0] | s_seen[1] | s_seen[2] | s_seen[3];
-        if (all) atomicOr(&seen_ws[b], all);
-        __threadfence();
-        s_last = atomicAdd(&ticket_ws[b], 1u) == (unsigned int)(segs - 1) ? 1u : 0u;
+    if (tid < W) {
+        unsigned int all = 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) all |= s_seen[i];
+        mask[(size_t)b * W + tid] = ((all >> tid) & 1u) ? 0 : 1;
     }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const unsigned int all = atomicOr(&seen_ws[b], 0u);       // the returned value of a device-scope atomic: every block's OR is in it
-    if (tid < W) mask[(size_t)b * W + tid] = ((all >> tid) & 1u) ? 0 : 1;
-    __syncthreads();
-    if (tid == 0) {
-        seen_ws[b] = 0u;
-        ticket_ws[b] = 0u;
-    }
-}
-}  // namespace ampnet
-
-namespace ampnet {
-// scratch of pad_mask_kernel: 2 x 4096 zero-initialised words per device, allocated on first use (stateless otherwise: the kernel leaves it zero)
-static unsigned int *pad_mask_scratch()
-{
-    static unsigned int *ws[16] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!ws[dev]) {
-        unsigned int *p = nullptr;
-        if (hipMalloc(&p, 2 * 4096 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 2 * 4096 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-        ws[dev] = p;
-    }
-    return ws[dev];
 }
 }  // namespace ampnet
 
 extern "C" int ampnet_pad_mask_i64(const long long *targets, int B, int P, int W, uint8_t *mask, void *stream)
 {
     AMPNET_REQUIRE(targets && mask, "ampnet_pad_mask_i64: null pointer");
-    AMPNET_REQUIRE(B >= 1 && B <= 4096 && P >= 1 && W >= 1 && W <= 32 && P % W == 0, "ampnet_pad_mask_i64: B=%d P=%d W=%d (B <= 4096, W <= 32, P %% W == 0)", B, P, W);
-    unsigned int *ws = ampnet::pad_mask_scratch();
-    if (!ws) return ampnet::fail(AMPNET_E_LAUNCH, "ampnet_pad_mask_i64: scratch allocation failed");
-    int segs = (P + 2047) / 2048;                              // ~2048 elements per block: a few blocks per CU at B = 64
-    if (segs > 16) segs = 16;
-    hipLaunchKernelGGL(ampnet::pad_mask_kernel, dim3(segs, B), dim3(256), 0, (hipStream_t)stream, targets, P, W, mask, ws, ws + 4096);
+    AMPNET_REQUIRE(B >= 1 && P >= 1 && W >= 1 && W <= 32 && P % W == 0, "ampnet_pad_mask_i64: B=%d P=%d W=%d (W <= 32, P %% W == 0)", B, P, W);
+    hipLaunchKernelGGL(ampnet::pad_mask_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, targets, P, W, mask);
     return ampnet::check_launch("pad_mask_kernel");
 }

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
     constexpr int TXN = CX / 32, TYN = CY / 32;
     constexpr int WXN = (TXN == 4 && TYN == 2) ? 4 : 2, WYN = 4 / WXN;
     constexpr int TXW = TXN / WXN, TYW = TYN / WYN;
-    constexpr int STAGE = 256;                      // the four W waves stage; the D waves only compute and store
+    constexpr int STAGE = FBB_THREADS;              // all eight waves stage (two register sets of loads in flight per thread, see the loop): the
+                                                    // D waves' waits are on loads two blocks old, older than any store they still have pending
     constexpr int QX = CX / 4, QY = CY / 4, SX = STAGE / QX, SY = STAGE / QY;
     constexpr int NIX = ROWS / SX, NIY = ROWS / SY;
     static_assert((ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
@@ -142,35 +143,37 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
         return open_item(p.item + 1, p);
     };
 
-    // the z tensors may be stored as bf16 (precision mode 3): 8-byte loads, widened on arrival; everything downstream is unchanged
-    constexpr bool zg_bf = ZG, zp_bf = ZP;
-    auto load_z4 = [](const float *base, size_t elem, bool bf) -> f32x4 {
-        if (bf) {
-            const bf16x4 v = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(base) + elem);
-            return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-        }
-        return *reinterpret_cast<const f32x4 *>(base + elem);
+    // the z tensors may be stored as bf16 (precision mode 3): 8-byte loads, kept as they arrive and widened when the tile is written to LDS.
+    // Two register sets: the loads of block n + 2 are issued while block n + 1 is still in flight (see the loop) -- with one set a CU has
+    // 16 .. 24 KB on the wire, which at the ~1 us of a loaded HBM round trip caps the kernel near 5 TB/s whatever the format (Little's law:
+    // the bf16-stored tensors moved half the bytes in the same time).
+    using ZGT = std::conditional_t<ZG, bf16x4, f32x4>;
+    using ZPT = std::conditional_t<ZP, bf16x4, f32x4>;
+    struct Regs {
+        f32x4 dy[NIX];
+        ZGT xz[NIX];
+        ZPT yz[NIY];
     };
-    f32x4 rx_dy[NIX], rx_z[NIX], ry_z[NIY];
-    auto load_regs = [&](const Pos &p) {
+    auto widen = [](const auto &v) -> f32x4 { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; };
+    auto load_regs = [&](const Pos &p, Regs &R) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            rx_z[i] = load_z4(a.g.z, rr * CX + 4 * cqx, zg_bf);
+            if (!x_act) R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
+            R.xz[i] = *reinterpret_cast<const ZGT *>(reinterpret_cast<const std::conditional_t<ZG, __bf16, float> *>(a.g.z) + rr * CX + 4 * cqx);
         }
         if (!GRAM) {
 #pragma unroll
             for (int i = 0; i < NIY; ++i) {
                 const int row = p.row0 + rsy + SY * i;
                 const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-                ry_z[i] = load_z4(a.prev.z, rr * CY + 4 * cqy, zp_bf);
+                R.yz[i] = *reinterpret_cast<const ZPT *>(reinterpret_cast<const std::conditional_t<ZP, __bf16, float> *>(a.prev.z) + rr * CY + 4 * cqy);
             }
         }
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
-    auto write_lds = [&](int buf, const Pos &p) {
+    auto write_lds = [&](int buf, const Pos &p, const Regs &R) {
         __bf16 *g = sG + buf * ROWS * LDG;
         __bf16 *y = sY + buf * ROWS * LDY;
         float *z = sZ + buf * ROWS * LDZ;
@@ -178,24 +181,26 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
         for (int i = 0; i < NIX; ++i) {
             const int lrow = rsx + SX * i, row = p.row0 + lrow;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 xz = widen(R.xz[i]);
             if (row < p.row_end) {
                 if (x_act) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[c] = fmaxf(fmaf(rx_z[i][c], p2[c], p3[c]), 0.f);
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaxf(fmaf(xz[c], p2[c], p3[c]), 0.f);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[c] = fmaf(rx_dy[i][c], p1[c], fmaf(rx_z[i][c], p2[c], p3[c]));
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaf(R.dy[i][c], p1[c], fmaf(xz[c], p2[c], p3[c]));
                 }
                 dbacc += xv;
             }
             *reinterpret_cast<bf16x4 *>(g + lrow * LDG + 4 * cqx) = to_bf16x4(xv);
-            if (GRAM && NEED_Z) *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqx) = rx_z[i];     // CX == CY here
+            if (GRAM && NEED_Z) *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqx) = xz;     // CX == CY here
         }
         if (!GRAM) {
 #pragma unroll
             for (int i = 0; i < NIY; ++i) {
                 const int lrow = rsy + SY * i, row = p.row0 + lrow;
-                f32x4 yv = ry_z[i];
+                const f32x4 yz = widen(R.yz[i]);
+                f32x4 yv = yz;
                 if (y_act) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) yv[c] = fmaxf(fmaf(yv[c], ys[c], yt[c]), 0.f);
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
                 }
                 if (!(row < p.row_end)) yv = f32x4{0.f, 0.f, 0.f, 0.f};        // rows past the block's end contribute nothing to dW
                 *reinterpret_cast<bf16x4 *>(y + lrow * LDY + 4 * cqy) = to_bf16x4(yv);
-                if (NEED_Z) *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqy) = ry_z[i];
+                if (NEED_Z) *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqy) = yz;
             }
         }
     };
@@ -233,23 +238,42 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
     const bool do_part = a.part_a != nullptr;
     float s_a = 0.f, s_b = 0.f;
 
-    Pos cur, nxt;
+    // Positions of blocks n (in LDS), n + 1 and n + 2 (in registers, in flight).  A tail position that does not exist repeats the last
+    // real one: the loads are issued unconditionally (a conditional load would make every wait in the loop a vmcnt(0), which is the
+    // one-deep pipeline again) and their data is simply not written.
+    Pos cur, nxt, nx2;
     bool live = open_item(item_begin, cur);
-    if (live && w_role) load_regs(cur);
+    bool more1 = false, more2 = false;
+    nxt = cur;
+    if (live) more1 = advance(nxt);
+    if (!more1) nxt = cur;
+    nx2 = nxt;
+    if (more1) more2 = advance(nx2);
+    if (!more2) nx2 = nxt;
+    Regs S0, S1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every constant has landed before the loop (see pw_bwd_fused.hip)
+    if (live) {
+        load_regs(cur, S0);
+        load_regs(nxt, S1);
+    }
     __syncthreads();                     // sWt staged
-    if (live && w_role) write_lds(0, cur);
+    if (live) {
+        write_lds(0, cur, S0);
+        load_regs(nx2, S0);
+    }
     __syncthreads();
     int buf = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every constant has landed before the loop (see pw_bwd_fused.hip)
-    while (live) {
-        nxt = cur;
-        const bool more = advance(nxt);
-        if (more && w_role) load_regs(nxt);
+    // one block of rows: compute block n from LDS, write block n + 1 (register set A) into the other buffer, refill A with block n + 3
+    // The two roles run the loop as two separate instantiations (role_tag): the wait for a register set is then a static count of the
+    // role's own younger memory operations (W: the other set's loads; D: those + its 32 stores) instead of the conservative merge of
+    // both paths, which made the D waves wait for the stores they had just issued.  Same number of barriers on both sides.
+    auto step = [&](Regs &A, auto role_tag) {
+        constexpr bool W_ROLE = decltype(role_tag)::value;
         const __bf16 *g = sG + buf * ROWS * LDG;
         const __bf16 *y = GRAM ? g : sY + buf * ROWS * LDY;
         constexpr int LDYY = GRAM ? LDG : LDY;
         const float *z = sZ + buf * ROWS * LDZ;
-        if (w_role) {
+        if constexpr (W_ROLE) {
 #pragma unroll
             for (int s2 = 0; s2 < ROWS / 16; ++s2) {
                 bf16x8 xa[TXW], yb[TYW];
@@ -314,11 +338,32 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
             if (valid >= 32) finish(std::true_type{});
             else finish(std::false_type{});
         }
-        if (more && w_role) write_lds(buf ^ 1, nxt);
+        Pos nx3 = nx2;
+        const bool more3 = more2 && advance(nx3);
+        if (!more3) nx3 = nx2;
+        if (more1) write_lds(buf ^ 1, nxt, A);
+        load_regs(nx3, A);
         __syncthreads();
         buf ^= 1;
         cur = nxt;
-        live = more;
+        nxt = nx2;
+        nx2 = nx3;
+        live = more1;
+        more1 = more2;
+        more2 = more3;
+    };
+    if (w_role) {
+        while (live) {
+            step(S1, std::true_type{});
+            if (!live) break;
+            step(S0, std::true_type{});
+        }
+    } else {
+        while (live) {
+            step(S1, std::false_type{});
+            if (!live) break;
+            step(S0, std::false_type{});
+        }
     }
 
     // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
@@ -337,7 +382,7 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
             }
     }
     if (a.dbpart) {
-        if (w_role) *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
         __syncthreads();
         if (tid < CX) {
             float s = 0.f;
@@ -370,7 +415,7 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
 template <int CX, int CY, int ROWS, bool GRAM, bool YACT, bool ADD, bool DROP, bool ZG, bool ZP>
 static int launch_bf16_z(const PwBwd &a, hipStream_t st)
 {
-    constexpr int SX = 256 / (CX / 4);
+    constexpr int SX = FBB_THREADS / (CX / 4);
     constexpr size_t red_floats = (size_t)(CX * SX > 8 * CY ? CX * SX : 8 * CY);
     constexpr size_t lds = (size_t)2 * ROWS * (CX + 32) * 2 + (GRAM ? 0 : (size_t)2 * ROWS * (CY + 32) * 2) + (YACT ? (size_t)2 * ROWS * (CY + 4) * 4 : 0) +
                            (size_t)CY * (CX + 8) * 2 + red_floats * 4;

@@ -195,12 +195,19 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     };
 
     f32x4 rx_dy[NIX], rx_z[NIX], ry_z[NIY];
+    // lane offsets (floats) inside a block of rows: row (rsx + SX i), columns 4 cqx ..; the block's first row is workgroup-uniform, so a
+    // full block is addressed as (uniform base in SGPRs) + (32-bit lane offset) + (compile-time i * SX * CX): no 64-bit VALU address
+    // arithmetic and no row clamps per load (99 VALU instructions for 20 loads before -- and VALU time is matrix-pipe time here)
+    // (Tried in round 3 and dropped: buffer addressing for these loads -- resource in SGPRs, one constant VGPR offset, SALU row offsets, i.e.
+    // zero VALU instructions per load instead of ~5 for the 64-bit flat address -- made every instantiation 3 .. 10 % SLOWER on the MI355X
+    // in a same-box A/B (gpurun_out r3j: <128,64> 439 -> 480 us, <64,64> 245 -> 291 us), as did reading the inputs from an L2-resident
+    // window, which changed nothing: the loads are not what this kernel waits for.)
     auto load_regs = [&](const Pos &p) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
             size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            if (a.dbg_row_wrap) rr %= (size_t)a.dbg_row_wrap;
+            if (a.dbg_row_wrap) rr &= (size_t)(a.dbg_row_wrap - 1);       // power of two
             if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
             if (has_bn || x_act) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
         }
@@ -209,12 +216,13 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             for (int i = 0; i < NIY; ++i) {
                 const int row = p.row0 + rsy + SY * i;
                 size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-                if (a.dbg_row_wrap) rr %= (size_t)a.dbg_row_wrap;
+                if (a.dbg_row_wrap) rr &= (size_t)(a.dbg_row_wrap - 1);
                 ry_z[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
             }
         }
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    const bool want_db = a.dbpart != nullptr;          // uniform: the layers without a bias skip 32 adds per block
     auto write_lds = [&](int buf, const Pos &p) {
         float *g = sG + buf * ROWS * LDG, *z = sZ + buf * ROWS * LDZ;
 #pragma unroll
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 } else {
                     xv = rx_dy[i];
                 }
-                dbacc += xv;
+                if (want_db) dbacc += xv;
             }
             *reinterpret_cast<f32x4 *>(g + (rsx + SX * i) * LDG + 4 * cqx) = xv;
             if (same && !SACT) *reinterpret_cast<f32x4 *>(z + (rsx + SX * i) * LDZ + 4 * cqx) = rx_z[i];   // CX == CY here

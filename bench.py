@@ -71,11 +71,11 @@ def profile_read():
     return out
 
 
-def pmc_traffic_for(name, rows=None):
+def pmc_traffic_for(name, rows=None, table="pmc_traffic.json"):
     """HBM bytes per launch (read + write) of the kernel bench.py calls `name`, from the rocprofv3 PMC passes summarised
-    in profiles/pmc_traffic.json (profiles/pmc_traffic.py; FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact).  None when the
-    file or an unambiguous match is missing."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    in profiles/pmc_traffic.json (profiles/pmc_traffic.py; FETCH_SIZE x 2 on gfx950, WRITE_SIZE exact; the bf16_store step has its own
+    table).  None when the file or an unambiguous match is missing."""
+    path = os.path.join(ROOT, "profiles", table)
     if not os.path.exists(path):
         return None
     table = json.load(open(path))
@@ -85,12 +85,12 @@ def pmc_traffic_for(name, rows=None):
     return round(v["read_bytes"] + (v["write_bytes"] or 0.0))
 
 
-def pmc_counters_for(name, rows=None):
+def pmc_counters_for(name, rows=None, tables=("pmc_traffic.json", "r03_pmc_counters.json")):
     """(matrix-pipe busy fraction, shader clock in GHz) of the kernel bench.py calls `name`, from the rocprofv3 SQ passes summarised in
     profiles/r02_pmc_counters.json (profiles/pmc_counters.py): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), i.e. at the
     clock the chip actually held -- roofline.frac prices the same kernel against the 2.4 GHz peak.  None when not collected."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    cpath = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+    tpath = os.path.join(ROOT, "profiles", tables[0])
+    cpath = os.path.join(ROOT, "profiles", tables[1])
     if not (os.path.exists(tpath) and os.path.exists(cpath)):
         return None
     table = json.load(open(tpath))
@@ -103,10 +103,22 @@ def pmc_counters_for(name, rows=None):
     return {"mfma_busy": round(c["mfma_busy"], 4), "sclk_ghz": round(c.get("sclk_ghz", 0.0), 3), "launch_us_under_pmc": round(c.get("duration_us", 0.0), 1)}
 
 
-def roofline_from(rows, work_rows=None):
+def roofline_from(rows, work_rows=None, tables=("pmc_traffic.json", "r03_pmc_counters.json"), hbm_from_pmc=False):
+    """The roofline object of the kernel with the largest share of the profiled steps.  hbm_from_pmc (the bf16 legs, which are HBM-bound):
+    achieved = PMC HBM bytes per launch / launch time against the 8 TB/s peak, algorithmic bytes next to it."""
     if not rows:
         return None
     top = max(rows, key=lambda r: r["ms"])
+    if hbm_from_pmc:
+        per_ms = top["ms"] / top["calls"]
+        traffic = pmc_traffic_for(top["name"], work_rows, tables[0])
+        alg = top["bytes"] / top["calls"]
+        used = traffic if traffic else alg
+        ach = used / (per_ms * 1e-3) / 1e9
+        return dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(ach / PEAK_HBM_GBPS, 4),
+                    traffic=traffic, bytes_source="pmc" if traffic else "algorithmic (no PMC table for this mode)", algorithmic_bytes=round(alg),
+                    mfma_busy=pmc_counters_for(top["name"], work_rows, tables), tflops=round(top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12, 1),
+                    launch_ms=round(per_ms, 4), launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     per_ms = top["ms"] / top["calls"]
     intensity = top["flops"] / max(top["bytes"], 1.0)
     is_bf16 = top["name"].endswith(" bf16")
@@ -114,12 +126,12 @@ def roofline_from(rows, work_rows=None):
     if intensity >= peak_tf * 1e3 / PEAK_HBM_GBPS:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
         return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s",
-                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"], work_rows), mfma_busy=pmc_counters_for(top["name"], work_rows),
+                    frac=round(ach / peak_tf, 4), traffic=pmc_traffic_for(top["name"], work_rows, tables[0]), mfma_busy=pmc_counters_for(top["name"], work_rows, tables),
                     algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
                     launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     ach = top["bytes"] / top["calls"] / (per_ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=pmc_traffic_for(top["name"], work_rows), launch_ms=round(per_ms, 4), launches=int(top["calls"]),
+                frac=round(ach / PEAK_HBM_GBPS, 4), traffic=pmc_traffic_for(top["name"], work_rows, tables[0]), launch_ms=round(per_ms, 4), launches=int(top["calls"]),
                 share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
 
 
@@ -413,6 +425,64 @@ def self_check(mode, B, args, rank, world, losses, n_warm, first_terms):
     return out
 
 
+def syncbn_probe_child(steps):
+    """Runs in a child process (`bench.py --probe syncbn`): ONE rank on the `nccl` backend (RCCL) with AMPNET_FORCE_COLLECTIVES=1, the
+    BASELINE configs[2] step with and without global-batch BatchNorm.  With one rank every collective is the identity, so the difference is
+    the HOST cost of the exchange path: 36 C -> Python callbacks -> torch.distributed calls per step + the loss all-reduce (no wire time)."""
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    synth, T = sub("synthetic"), sub("trainer")
+    B = 64
+    pc, tg, cent, _ = synth.sample_batch(100, B, N_POINTS, max_w=N_WIN)
+    x = torch.from_numpy(np.ascontiguousarray(pc.transpose(0, 3, 1, 2))).to(dev)
+    t = torch.from_numpy(np.ascontiguousarray(tg.transpose(0, 2, 1))).to(dev)
+    centd = torch.from_numpy(cent).to(dev)
+    cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device=dev)
+    out = {}
+    for tag, sync in (("gradient_allreduce_only", False), ("global_batch_batchnorm", True)):
+        enc, att = build_models(dev, train=True)
+        tr = T.Trainer(enc, att, lr=1e-3, class_w=cw)
+        if sync:
+            assert T.enable_sync_batchnorm()
+        for _ in range(2):
+            tr.step(x, t, centd)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(x, t, centd)
+        torch.cuda.synchronize(dev)
+        out[tag] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        if sync:
+            T.disable_sync_batchnorm()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps({"probe": "syncbn", "ms_per_step": out}), flush=True)
+
+
+def syncbn_probe(steps):
+    """Host cost of the data-parallel exchanges on RCCL without a second GPU (the child process above; never an exec of this process)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", AMPNET_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", "syncbn", "--steps", str(steps)], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        ms = json.loads(line[-1])["ms_per_step"]
+        return {"backend": "rccl (nccl), one rank, AMPNET_FORCE_COLLECTIVES=1: every collective is the identity, the difference is host cost",
+                "ms_per_step_plain_exchange": ms["gradient_allreduce_only"], "ms_per_step_global_batch_batchnorm": ms["global_batch_batchnorm"],
+                "host_ms_of_36_batchnorm_exchanges_and_loss_allreduce": round(ms["global_batch_batchnorm"] - ms["gradient_allreduce_only"], 4)}
+    except Exception as e:                          # the probe is informational: never fail the bench line over it
+        return {"error": repr(e)[:300]}
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` from a plain shell: run this script as N ranks under torch.distributed.run (one process per
     GPU, rendezvous on 127.0.0.1), pass the ranks' output through (rank 0 prints the JSON line) and return the launcher's
@@ -462,10 +532,13 @@ def main():
                                                            "(36 more latency-bound collectives per step; default: per-rank statistics)")
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
+    ap.add_argument("--probe", choices=["syncbn"], default=None, help="internal: child-process probes of the default run")
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train", "bf16_store"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
                     help="MFMA operand precision: fp32 (headline), bf16 = forward per-point layers, bf16_train = forward + fused backward (fp32 accumulate)")
     args = ap.parse_args()
 
+    if args.probe == "syncbn":
+        return syncbn_probe_child(max(args.steps, 3))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves.  Nothing in this process has touched the GPU yet
         # (importing torch does not initialise HIP), and the ranks are fresh children, never an exec of this process.
@@ -608,13 +681,24 @@ def main():
                 step()
             sync()
             dt_bf = time.perf_counter() - t3
+            # the leg's own roofline: HIP events around every launch for a few steps in this mode
+            L.ampnet_profile_enable(1)
+            for _ in range(min(args.steps, 5)):
+                step()
+            torch.cuda.synchronize(dev)
+            rows_bf = profile_read()
+            L.ampnet_profile_enable(0)
         finally:
             sub("_lib").set_matrix_precision("fp32")
         if dist is not None:
             tt = torch.tensor([dt_bf], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_bf = float(tt.item())
-        return {"ms_per_step": round(dt_bf / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1), "note": note}
+        tables = (f"r03_pmc_traffic_{prec}.json", f"r03_pmc_counters_{prec}.json")
+        return {"ms_per_step": round(dt_bf / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1), "note": note,
+                "roofline": roofline_from(rows_bf, B * N_WIN * N_POINTS, tables, hbm_from_pmc=True),
+                "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / min(args.steps, 5), 4), tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 1),
+                                        gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows_bf], key=lambda r: -r["ms_per_step"])[:5]}
 
     bf16_leg = bf16_train_leg = bf16_store_leg = None
     if mode == "train" and args.precision == "fp32":
@@ -635,12 +719,13 @@ def main():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         ar_ms = (time.perf_counter() - t4) / args.steps * 1e3
-    incl = fps = infer = None
+    incl = fps = infer = dp_probe = None
     if mode == "train" and world == 1 and not args.no_extra_legs:
         incl = train_loop_inclusive(enc, att, trainer_mod, B, dev, max(args.steps // 2, 3))
         fps = fps_leg(dev, 16, max(args.steps // 2, 3), 1, 200, 0.0 if args.no_cpu_baseline else 5.0)
         fps["many_clouds"] = fps_many_leg(dev, args.steps, 210)
         infer = inference_leg(enc, att, dev, args.steps)
+        dp_probe = syncbn_probe(min(args.steps, 8))
 
     if rank == 0:
         pts_step = B * N_WIN * N_POINTS
@@ -663,7 +748,7 @@ def main():
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
-            "train_loop_inclusive": incl, "fps": fps, "inference": infer,
+            "train_loop_inclusive": incl, "fps": fps, "inference": infer, "data_parallel_host_cost": dp_probe,
             "check": check,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,

@@ -26,7 +26,11 @@ def per_dispatch(dirname, counter):
     return out
 
 
-def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None):
+FPS_CASES = {"stage2_256x8192_to_4096": (256, 8192, 4096), "stage1_16x16384_to_8192": (16, 16384, 8192),
+             "stage1_256x16384_to_8192": (256, 16384, 8192), "stream_8x32768_to_8192": (8, 32768, 8192)}
+
+
+def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None, fps_cases=None):
     fe, wr = per_dispatch(src, "FETCH_SIZE"), per_dispatch(src, "WRITE_SIZE")
     res = {}
     for sym, rows in fe.items():
@@ -64,6 +68,18 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None):
                     events[name] = {"launches": len(rd), "read_bytes": sum(rd) / len(rd) * 1024 * 2, "read_bytes_uncorrected": sum(rd) / len(rd) * 1024,
                                     "write_bytes": (sum(ww) / len(ww) * 1024) if ww else None, "symbol": sym.split("(")[0].replace("void ", ""),
                                     "workload_rows": 16 * 8192, "floor_bytes": {"fps_kernel": 16 * (8192 * 12 + 4096 * 4), "knn_kernel": 16 * (8192 * 12 + 4096 * 4 + 4096 * 32 * 4)}[name]}
+    # bench.py fps.many_clouds: one pass directory per case, event name "<kernel>:<case>"
+    for tag, d in (fps_cases or {}).items():
+        ff, fw = per_dispatch(d, "FETCH_SIZE"), per_dispatch(d, "WRITE_SIZE")
+        B, N, S = FPS_CASES[tag]
+        for sym, rows in ff.items():
+            for name in ("fps_stream_kernel", "fps_kernel"):
+                if name in sym and not (name == "fps_kernel" and "fps_stream_kernel" in sym):
+                    rd = [v for _, v in rows]
+                    ww = [v for _, v in fw.get(sym, [])]
+                    events[f"{name}:{tag}"] = {"launches": len(rd), "read_bytes": sum(rd) / len(rd) * 1024 * 2, "read_bytes_uncorrected": sum(rd) / len(rd) * 1024,
+                                               "write_bytes": (sum(ww) / len(ww) * 1024) if ww else None, "symbol": sym.split("(")[0].replace("void ", ""),
+                                               "workload_rows": B * N, "floor_bytes": B * (N * 12 + S * 4), "algorithmic_bytes": float(B) * S * N * 16}
     res["events"] = events
     res["workload_rows"] = rows_per_launch          # rows (points) every point-layer launch of the profiled step processes
     json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
@@ -71,10 +87,15 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None):
 
 
 if __name__ == "__main__":
-    fps = None
+    fps, cases = None, {}
     argv = list(sys.argv[1:])
     if "--fps" in argv:
         i = argv.index("--fps")
         fps = argv[i + 1]
         del argv[i:i + 2]
-    main(argv[0], argv[1], *(int(a) for a in argv[2:3]), fps_src=fps)
+    while "--fps-case" in argv:                     # --fps-case <tag>=<dir>
+        i = argv.index("--fps-case")
+        tag, d = argv[i + 1].split("=", 1)
+        cases[tag] = d
+        del argv[i:i + 2]
+    main(argv[0], argv[1], *(int(a) for a in argv[2:3]), fps_src=fps, fps_cases=cases)

@@ -4,7 +4,7 @@ baseline_light_cls.npz, made by tests/golden/make_golden.py:sec_baseline_cls; th
 committed, DESIGN.md section 7, so the modules are what is pinned).
 Bars: eval log-probabilities / feature transform 1e-4 absolute; train-mode (dropout 0, B = 16) loss terms 1e-4 relative, outputs 1e-3,
 running statistics 1e-3, every gradient within 3 x (the reference's own float32-to-float64 distance, both runs in the fixture) + 2e-2 of its
-norm of the reference's float64 gradient (B = 16 rows in the FC BatchNorms make the input T-Net's tensors noisy in the reference itself); dropout 0.3 against a float64 restatement with the same keep-mask."""
+norm of the reference's float64 gradient (B = 16 rows in the FC BatchNorms make the input T-Net's tensors noisy in the reference itself); dropout 0.3 against a float64 restatement with the same keep-mask, bar 3 x (float32 evaluation of that restatement) + 2e-2."""
 import os
 import sys
 
@@ -103,7 +103,8 @@ def test_train_step_matches_reference_autograd(golden, synth, tag, modname, pdim
 
 
 def _f64_forward(sd, x, pdim, drop_keep, drop_p):
-    """float64 restatement of ClassificationPointNet.forward in train mode (batch statistics) from torch ops; sd: state_dict in float64."""
+    """Restatement of ClassificationPointNet.forward in train mode (batch statistics) from torch ops in the dtype of x / sd (float64 = the
+    arbiter; float32 = the noise an fp32 evaluation of this graph carries)."""
     def lin_bn(h, pre, lin, bn, relu=True):
         w = sd[pre + lin + ".weight"]
         h = h @ w.reshape(w.shape[0], -1).t()
@@ -118,7 +119,7 @@ def _f64_forward(sd, x, pdim, drop_keep, drop_p):
         h = lin_bn(lin_bn(lin_bn(h, pre, "conv_1", "bn_1"), pre, "conv_2", "bn_2"), pre, "conv_3", "bn_3")
         p = h.reshape(Bn, N, -1).max(1).values
         p = lin_bn(lin_bn(p, pre, "fc_1", "bn_4"), pre, "fc_2", "bn_5")
-        return lin_bn(p, pre, "fc_3", None, relu=False).reshape(Bn, k, k) + torch.eye(k, dtype=torch.float64)
+        return lin_bn(p, pre, "fc_3", None, relu=False).reshape(Bn, k, k) + torch.eye(k, dtype=x.dtype)
     Bn, N = x.shape[0], x.shape[1]
     T = tnet(x[:, :, :pdim].reshape(-1, pdim), "base_pointnet.input_transform.", pdim, Bn, N)
     h = torch.cat([torch.bmm(x[:, :, :pdim], T), x[:, :, pdim:]], 2).reshape(-1, 9)
@@ -147,6 +148,7 @@ def test_dropout_step_matches_float64_autograd(synth, tag, modname, pdim, base):
     y = torch.from_numpy((synth.uniform(88, (Bn,), 0.0, 1.0) * N_CLS).astype(np.int64).clip(0, N_CLS - 1)).cuda()
     sd64 = {k: v.detach().double().cpu().clone().requires_grad_("running" not in k and "num_batches" not in k) for k, v in net.state_dict().items()
             if "num_batches" not in k}
+    sd32 = {k: v.detach().float().clone().requires_grad_(v.requires_grad) for k, v in sd64.items()}
     seed = net.seed & 0xFFFFFFFF
     out, ft = net(x)
     loss = torch.nn.functional.nll_loss(out, y) + 0.001 * torch.norm(torch.eye(64, device="cuda") - torch.bmm(ft, ft.transpose(2, 1)))
@@ -157,13 +159,19 @@ def test_dropout_step_matches_float64_autograd(synth, tag, modname, pdim, base):
     o64, T64 = _f64_forward(sd64, x.double().cpu(), pdim, keep, drop_p)
     l64 = torch.nn.functional.nll_loss(o64, y.cpu()) + 0.001 * torch.norm(torch.eye(64, dtype=torch.float64) - torch.bmm(T64, T64.transpose(2, 1)))
     l64.backward()
+    # the same graph in float32 on the CPU: how far an fp32 evaluation sits from the float64 one (B = 16 rows in the FC BatchNorms amplify
+    # rounding in the input T-Net, as in test_train_step_matches_reference_autograd)
+    o32, T32 = _f64_forward(sd32, x.float().cpu(), pdim, keep.float(), drop_p)
+    l32 = torch.nn.functional.nll_loss(o32, y.cpu()) + 0.001 * torch.norm(torch.eye(64) - torch.bmm(T32, T32.transpose(2, 1)))
+    l32.backward()
     assert abs(loss.item() - l64.item()) <= 1e-4 * abs(l64.item()), (loss.item(), l64.item())
     assert (out.detach().double().cpu() - o64.detach()).abs().max().item() <= 1e-3
     gtot = np.sqrt(sum(float(v.grad.norm()) ** 2 for v in sd64.values() if v.grad is not None))
     worst = 0.0
     for k, p in net.named_parameters():
         w = sd64[k].grad
+        noise = (sd32[k].grad.double() - w).norm().item()
         err = (p.grad.double().cpu().reshape(w.shape) - w).norm().item()
         worst = max(worst, err / (w.norm().item() + 1e-5 * gtot))
-        assert err <= 3e-2 * w.norm().item() + 1e-5 * gtot, (k, err, w.norm().item())
+        assert err <= 3.0 * noise + 2e-2 * w.norm().item() + 1e-5 * gtot, (k, err, noise, w.norm().item())
     print(f"{tag} with dropout: worst relative gradient error vs float64 autograd {worst:.2e}")

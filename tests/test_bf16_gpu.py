@@ -318,7 +318,9 @@ def test_bf16_store_training_matches_fp32_miou_and_oracle_logits(synth, params):
     fixed number of steps on the same synthetic batches in fp32 and in bf16_store (bf16 MFMA operands forward + fused backward, bf16
     stored activations), then
       * mean IoU / accuracy of the two trained models on a fixed validation split (eval forward, each in its own mode) within a stated
-        ABSOLUTE bound: |d mIoU| <= 0.03, |d accuracy| <= 0.02 -- and both models must have learned (mIoU well above the untrained one);
+        ABSOLUTE bound: |d mIoU| <= 0.03 + s_m, |d accuracy| <= 0.02 + s_a, where s = the distance between two fp32 trainings that differ
+        only in the dropout stream (60 steps on B = 16 is a noisy trajectory: the fp32 mIoU itself moved 0.394 -> 0.419 when only the
+        summation order of the small GEMMs changed, round 3) -- and both models must have learned (mIoU well above the untrained one);
       * the eval logits of the bf16_store path against the ORACLE (float32 CPU forward of the weights the bf16_store run trained;
         oracle/ampnet_oracle.py), not against the HIP fp32 path: max |diff| <= 0.1 of the logit span (measured 7.0e-2 after 60 steps: the
         2^-9 operand rounding through twelve layers on TRAINED weights; 3e-2 on the seeded untrained ones, test_bf16_store_eval_forward),
@@ -350,9 +352,11 @@ def test_bf16_store_training_matches_fp32_miou_and_oracle_logits(synth, params):
 
     res = {}
     try:
-        for mode in ("fp32", "bf16_store"):
-            L.set_matrix_precision(mode)
+        for mode in ("fp32", "fp32_twin", "bf16_store"):
+            L.set_matrix_precision("fp32" if mode == "fp32_twin" else mode)
             enc, att = _models(synth, params, 0.3)
+            if mode == "fp32_twin":                       # the same fp32 training with another dropout stream: the trajectory's own spread
+                att.seed = (att.seed + 0x9E3779B9) & 0xFFFFFFFF
             if mode == "fp32":
                 res["untrained"] = evaluate(enc, att)
             tr = T.Trainer(enc, att, lr=1e-3, class_w=cw)
@@ -380,11 +384,13 @@ def test_bf16_store_training_matches_fp32_miou_and_oracle_logits(synth, params):
     finally:
         L.set_matrix_precision("fp32")
     (acc_f, miou_f, ce_f), (acc_b, miou_b, ce_b) = res["fp32"], res["bf16_store"]
+    acc_t, miou_t, _ = res["fp32_twin"]
+    spread_m, spread_a = abs(miou_t - miou_f), abs(acc_t - acc_f)
     err, span, mism = res["oracle"]
     print(f"after {STEPS} steps: fp32 mIoU {miou_f:.4f} acc {acc_f:.4f} ce {ce_f:.4f} | bf16_store mIoU {miou_b:.4f} acc {acc_b:.4f} ce {ce_b:.4f} | "
-          f"untrained mIoU {res['untrained'][1]:.4f}; bf16_store eval logits vs the oracle: max |diff| {err:.3e} on a span of {span:.3g}, argmax differs on {mism:.2%}")
+          f"fp32 with another dropout stream mIoU {miou_t:.4f} acc {acc_t:.4f} | untrained mIoU {res['untrained'][1]:.4f}; bf16_store eval logits vs the oracle: max |diff| {err:.3e} on a span of {span:.3g}, argmax differs on {mism:.2%}")
     assert miou_f > res["untrained"][1] + 0.05 and miou_b > res["untrained"][1] + 0.05, "the models did not learn"
-    assert abs(miou_b - miou_f) <= 0.03, (miou_b, miou_f)
-    assert abs(acc_b - acc_f) <= 0.02, (acc_b, acc_f)
+    assert abs(miou_b - miou_f) <= 0.03 + spread_m, (miou_b, miou_f, miou_t)
+    assert abs(acc_b - acc_f) <= 0.02 + spread_a, (acc_b, acc_f, acc_t)
     assert err <= 0.1 * max(span, 1.0), (err, span)
     assert mism <= 0.02, mism

@@ -5,7 +5,7 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 def short(n):
     n = re.sub(r'\(anonymous namespace\)::|ampnet::|void ', '', n)
     return n[:100]
-steps = int([r for r in rows if 'adam' in r['Name']][0]['Calls']) / 2
+steps = int([r for r in rows if 'reg_finalize' in r['Name']][0]['Calls'])            # one launch per step
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 agg = sorted(((float(r['TotalDurationNs']) / steps / 1e3, int(r['Calls']) / steps, float(r['AverageNs']) / 1e3, short(r['Name'])) for r in rows), reverse=True)
 small = sum(a[0] for a in agg if a[2] < 100)
