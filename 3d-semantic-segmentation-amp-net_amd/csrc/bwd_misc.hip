@@ -1,5 +1,7 @@
 // bwd_misc.hip -- the small backward kernels: BatchNorm-backward constants, MaxPool backward, a plain tiled
 // SGEMM for the [Q, <=4096] T-Net FC / attention projections, and the K<=12 input layers' weight gradients.
+#include <cstdlib>
+#include <cstdint>
 #include "bwd_misc.h"
 
 namespace ampnet {
@@ -324,6 +326,110 @@ __global__ __launch_bounds__(256 * SG_SK) void sgemm_small_kernel(SgArgs args)
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// sgemm_mfma: the same problems on the fp32 matrix pipe, without LDS staging and without dependent trips.
+// One workgroup of 16 waves per 32 x 32 output tile; the waves split K between them (contiguous ranges of 8-deep chunks) and every
+// wave feeds v_mfma_f32_32x32x2_f32 STRAIGHT from global memory: lane (r, h) supplies op(A)[m0 + r][k] and op(B)[k][n0 + r] for the
+// k values 8 c + 4 h + i, i = 0..3, of chunk c (any pairing of k values is a valid contraction order as long as both operands use the
+// same one).  An operand whose k runs along ROWS of the stored matrix (G and X of a weight gradient G^T X, W of a data gradient G W)
+// is four coalesced 128-byte row segments per chunk; one whose k is contiguous in memory (G of G W) is one 16-byte load per lane.
+// All loads of up to eight chunks per wave are issued before the first MFMA: K = 576 (the rows of a per-window problem) is ONE memory
+// round trip and <= 20 MFMAs per wave, where the VALU kernel above makes three load -> barrier -> multiply trips that are bound by
+// its LDS reads (4 ds_read_b32 per 4 FMAs, two 1024-thread workgroups per CU): 19 .. 46 us per launch there, the launch floor here.
+// The 16 partial tiles are summed through LDS in wave order: fixed order, no atomics, bitwise reproducible.
+// ----------------------------------------------------------------------------------------------------
+constexpr int SGM_WAVES = 16;
+constexpr int SGM_PASS = 8;              // chunks of 8 k values a wave has in flight per pass
+
+typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
+typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
+
+// four k values 8 c + 4 h + i of row / column x of an operand; kmaj: k contiguous in memory (element (x, k) at base[x * ld + k])
+__device__ __forceinline__ sg_f32x4 sgm_fetch(const float *__restrict__ base, int ld, bool kmaj, bool vec, int x, int X, int k, int K)
+{
+    sg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (x >= X) return v;
+    if (kmaj) {
+        const float *p = base + (size_t)x * ld + k;
+        if (vec && k + 3 < K) return *reinterpret_cast<const sg_f32x4 *>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k + i < K) v[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (k + i < K) v[i] = base[(size_t)(k + i) * ld + x];
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64 * SGM_WAVES) void sgemm_mfma_kernel(SgArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) float sgm_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sgm_smem);                       // [SGM_WAVES][16][64]
+    float (*rsum)[32] = reinterpret_cast<float (*)[32]>(sgm_smem + SGM_WAVES * 16 * 64);        // [SGM_WAVES][32]
+    const SgProblem &g = args.p[blockIdx.z];
+    const int M = g.M, N = g.N, K = g.K;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= M || n0 >= N) return;                             // uniform per block: the grid covers the largest problem of the launch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const bool akm = g.ta == 0, bkm = g.tb != 0;                // k contiguous in memory
+    const bool avec = akm && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    const bool bvec = bkm && (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+    const int chunks = (K + 7) / 8;
+    const int per_wave = (chunks + SGM_WAVES - 1) / SGM_WAVES;
+    const int c_begin = min(wave * per_wave, chunks), c_end = min(c_begin + per_wave, chunks);
+    const bool do_rs = g.db != nullptr && blockIdx.x == 0;
+    sg_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float rs = 0.f;
+    for (int c0 = c_begin; c0 < c_end; c0 += SGM_PASS) {
+        sg_f32x4 av[SGM_PASS], bv[SGM_PASS];
+#pragma unroll
+        for (int u = 0; u < SGM_PASS; ++u) {
+            if (c0 + u < c_end) {                                // wave-uniform
+                const int k = 8 * (c0 + u) + 4 * h;
+                av[u] = sgm_fetch(g.A, g.lda, akm, avec, m0 + r, M, k, K);
+                bv[u] = sgm_fetch(g.B, g.ldb, bkm, bvec, n0 + r, N, k, K);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SGM_PASS; ++u) {
+            if (c0 + u < c_end) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc, 0, 0, 0);
+                if (do_rs) rs += (av[u][0] + av[u][1]) + (av[u][2] + av[u][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][e][lane] = acc[e];
+    if (do_rs) {
+        rs += __shfl_xor(rs, 32);
+        if (h == 0) rsum[wave][r] = rs;
+    }
+    __syncthreads();
+    // thread -> one output element: e = tid >> 6 (accumulator register), lane as in the MFMA output map
+    {
+        const int e = tid >> 6;
+        const int gm = m0 + (e & 3) + 8 * (e >> 2) + 4 * h, gn = n0 + r;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SGM_WAVES; ++w) v += red[w][e][lane];
+        if (gm < M && gn < N) {
+            float *d = g.C + (size_t)gm * g.ldc + gn;
+            *d = g.accumulate ? *d + v : v;
+        }
+    }
+    if (do_rs && tid < 32 && m0 + tid < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SGM_WAVES; ++w) v += rsum[w][tid];
+        g.db[m0 + tid] = v;
+    }
+}
+
 static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
 {
     AMPNET_REQUIRE(n >= 1 && n <= SG_MAX_PROBLEMS, "sgemm_small: %d problems", n);
@@ -340,9 +446,23 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
         bytes += 4.0 * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N);
     }
     if (n == 1) a.p[1] = a.p[0];
-    ProfScope prof("sgemm_small", flops, bytes, st);
-    hipLaunchKernelGGL(sgemm_small_kernel, dim3(gx, gy, n), dim3(256 * SG_SK), 0, st, a);
-    return check_launch("sgemm_small_kernel");
+    // AMPNET_SGEMM_VALU=1: the VALU kernel (A/B timing, tests/test_small_gemm_gpu.py compares the two)
+    static const bool valu = [] { const char *e = getenv("AMPNET_SGEMM_VALU"); return e && e[0] == '1'; }();
+    if (valu) {
+        ProfScope prof("sgemm_small", flops, bytes, st);
+        hipLaunchKernelGGL(sgemm_small_kernel, dim3(gx, gy, n), dim3(256 * SG_SK), 0, st, a);
+        return check_launch("sgemm_small_kernel");
+    }
+    constexpr size_t lds = (size_t)(SGM_WAVES * 16 * 64 + SGM_WAVES * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sgemm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "sgemm_mfma: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    ProfScope prof("sgemm_mfma", flops, bytes, st);
+    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3(gx, gy, n), dim3(64 * SGM_WAVES), lds, st, a);
+    return check_launch("sgemm_mfma_kernel");
 }
 
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
@@ -1149,3 +1269,15 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
 }
 
 }  // namespace ampnet
+
+// ---- the token-level products of the backward behind the C ABI (tests/test_small_gemm_gpu.py) ----------------------------------------
+extern "C" int ampnet_small_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                                     int accumulate, float *row_sums, void *stream)
+{
+    AMPNET_REQUIRE(A && B && C, "ampnet_small_gemm_f32: null pointer");
+    AMPNET_REQUIRE(M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "ampnet_small_gemm_f32: M=%d N=%d K=%d lda=%d ldb=%d ldc=%d", M, N, K, lda, ldb, ldc);
+    ampnet::SgProblem p = {M, N, K, trans_a, trans_b, lda, ldb, ldc, accumulate, A, B, C};
+    p.db = row_sums;
+    return ampnet::sgemm_launch(&p, 1, (hipStream_t)stream);
+}
+

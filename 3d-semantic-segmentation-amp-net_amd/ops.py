@@ -276,6 +276,29 @@ def pad_mask(targets, W):
     return mask
 
 
+def small_gemm(A, B, trans_a=False, trans_b=False, out=None, accumulate=False, want_row_sums=False):
+    """C (+)= op(A) op(B) on the kernel the backward uses for its token-level products (include/ampnet_hip.h: ampnet_small_gemm_f32).
+    A, B: 2-D float32 GPU tensors whose rows are contiguous (a column slice of a wider matrix is fine: the leading dimension is its stride)."""
+    _lib.require_gpu(A, "A")
+    _lib.require_gpu(B, "B")
+    for name, x in (("A", A), ("B", B)):
+        if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+            raise _lib.AmpnetError(f"small_gemm: {name} must be a 2-D float32 tensor with contiguous rows, got {tuple(x.shape)} {x.dtype} strides {x.stride()}")
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[0], B.shape[1]) if trans_b else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise _lib.AmpnetError(f"small_gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    rs = torch.empty((M,), dtype=torch.float32, device=A.device) if want_row_sums else None
+    with torch.cuda.device(A.device):
+        vp = ctypes.c_void_p
+        rc = _lib.lib().ampnet_small_gemm_f32(int(trans_a), int(trans_b), M, N, K, vp(A.data_ptr()), A.stride(0), vp(B.data_ptr()), B.stride(0),
+                                              vp(out.data_ptr()), out.stride(0), int(accumulate), _lib.ptr(rs), _lib.stream_ptr(A.device))
+    _lib.check(rc, "ampnet_small_gemm_f32")
+    return (out, rs) if want_row_sums else out
+
+
 def reg_loss(feat_T, keep_G=False):
     """|| I - F F^T ||_F over the stack feat_T [n, 64, 64] -> device scalar tensor [1] (and G when keep_G)."""
     _lib.require_gpu(feat_T, "feat_T")
