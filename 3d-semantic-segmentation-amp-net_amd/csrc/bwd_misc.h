@@ -14,8 +14,11 @@ int axpy(const float *x, float alpha, size_t n, float *y, hipStream_t st);
 
 struct PwInputWgrad {
     const float *x = nullptr;                 // [rows, 9]
-    const float *dy = nullptr, *z = nullptr;  // [rows, 64]
-    int z_bf16 = 0;                           // z is a bf16 tensor (precision mode 3)
+    const float *dy = nullptr;                // [rows, 64]
+    // the layer's pre-BatchNorm output z is RECOMPUTED from the staged x rows (3 or 9 FMAs per element, the arithmetic of pw_input) instead of
+    // read back: the kernel sits on HBM, and z was half of its bytes
+    const float *W = nullptr, *T = nullptr;   // as PwInput: mode 0 W [64, 3]; mode 1 W [64, 12], T [.., 3, 3] per window
+    int mode = 0, perwin_slot_major = 0;
     const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, 64]
     float *dWeff = nullptr;                   // [Q, 64, 9]
     const int *win_off = nullptr;

@@ -668,7 +668,7 @@ int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
 // ----------------------------------------------------------------------------------------------------
 // input layers (K = 3 / 9): per-window dWeff[q][c][f] = sum_rows g[row][c] * x[row][f], lane = channel c
 // ----------------------------------------------------------------------------------------------------
-template <bool ZB> __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
+__global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
 {
     __shared__ float sx[256 * 9];
     __shared__ float red[4][64][9];
@@ -677,6 +677,22 @@ template <bool ZB> __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(
     const int row_begin = a.win_off[q], row_end = a.win_off[q + 1];
     const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
     const float p1 = a.P1[(size_t)slot * 64 + lane], p2 = a.P2[(size_t)slot * 64 + lane], p3 = a.P3[(size_t)slot * 64 + lane];
+    // effective weights of this lane's channel, exactly as pw_input forms them (pw_misc.hip)
+    float w[9];
+    if (a.mode == 0) {
+#pragma unroll
+        for (int f = 0; f < 9; ++f) w[f] = f < 3 ? a.W[lane * 3 + f] : 0.f;
+    } else {
+        const int pidx = a.perwin_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+        const float *T = a.T + (size_t)pidx * 9;
+#pragma unroll
+        for (int f = 0; f < 9; ++f) {
+            float v = a.W[lane * 12 + 3 + f];
+            if (f < 3) v += T[f * 3 + 0] * a.W[lane * 12 + 0] + T[f * 3 + 1] * a.W[lane * 12 + 1] + T[f * 3 + 2] * a.W[lane * 12 + 2];
+            w[f] = v;
+        }
+    }
+    const bool three = a.mode == 0;
     float acc[9];
 #pragma unroll
     for (int f = 0; f < 9; ++f) acc[f] = 0.f;
@@ -685,20 +701,25 @@ template <bool ZB> __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(
         __syncthreads();
         for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
         __syncthreads();
-        for (int i0 = wave; i0 < n; i0 += 32) {        // 8 rows per trip: 16 independent loads, then the FMAs
-            float dyv[8], zv[8];
+        for (int i0 = wave; i0 < n; i0 += 32) {        // 8 rows per trip: 8 independent loads, then the FMAs
+            float dyv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + 4 * u, n - 1);
-                const size_t o = (size_t)(base + i) * 64 + lane;
-                dyv[u] = a.dy[o];
-                zv[u] = ld_act_t<ZB>(a.z, o);
+                dyv[u] = a.dy[(size_t)(base + i) * 64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + 4 * u;
                 if (i < n) {
-                    const float g = fmaf(dyv[u], p1, fmaf(zv[u], p2, p3));
+                    float z = 0.f;
+                    if (three) {
+                        z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+                    }
+                    const float g = fmaf(dyv[u], p1, fmaf(z, p2, p3));
 #pragma unroll
                     for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, sx[i * 9 + f], acc[f]);
                 }
@@ -717,9 +738,9 @@ template <bool ZB> __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(
 
 int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.x && a.dy && a.z && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
-    if (a.z_bf16) hipLaunchKernelGGL(pw_input_wgrad_kernel<true>, dim3(a.Q), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(pw_input_wgrad_kernel<false>, dim3(a.Q), dim3(256), 0, st, a);
+    AMPNET_REQUIRE(a.x && a.dy && a.W && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
+    AMPNET_REQUIRE(a.mode == 0 || a.T, "pw_input_wgrad: mode 1 needs T");
+    hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(256), 0, st, a);
     return check_launch("pw_input_wgrad_kernel");
 }
 

@@ -159,7 +159,7 @@ struct EncRun {
         if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
         if (pool) { g.part_max = ws.part_max; g.part_amax = ws.part_amax; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
-        if (stats && !pool) {                                    // one partial per workgroup: bn_finalize in one stage (kernels.h)
+        if (stats) {                                             // one partial per workgroup: bn_finalize in one stage (kernels.h)
             g.part_rows = ws.part_rows;
             g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots).lanes;
         }
@@ -253,7 +253,7 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
     TRY(pw_gemm(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), e.st));
     TRY(e.finalize(bn0 + 1, false));
     TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true, bn0 + 2), e.st));
-    TRY(e.finalize(bn0 + 2, false, 0));
+    TRY(e.finalize(bn0 + 2, false));
     TRY(e.pool(bn0 + 2, pooled, arg, zext, true));
     // FC head on [Q, 256]
     TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, bn0 + 3), e.st));
@@ -340,7 +340,7 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
     TRY(pw_gemm(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), e.st));
     TRY(e.finalize(BN_C5, false));
     TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true, BN_C6), e.st));
-    TRY(e.finalize(BN_C6, false, 0));
+    TRY(e.finalize(BN_C6, false));
     TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, e.ws.zext_c, false));
 
     if (tr) {

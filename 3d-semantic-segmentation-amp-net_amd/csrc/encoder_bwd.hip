@@ -525,7 +525,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     {
         TRY(e.settle());                       // pw_input_wgrad reads bn_1's constants from memory
         PwInputWgrad w;
-        w.x = x; w.dy = b.dyB; w.z = f.z_c1; w.z_bf16 = e.zb ? 1 : 0;
+        w.x = x; w.dy = b.dyB; w.W = P[EP_CONV1]; w.T = f.T3; w.mode = 1; w.perwin_slot_major = 1;
         w.P1 = b.bn[BN_C1].P1; w.P2 = b.bn[BN_C1].P2; w.P3 = b.bn[BN_C1].P3;
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));
@@ -541,7 +541,7 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
     {
         TRY(e.settle());
         PwInputWgrad w;
-        w.x = x; w.dy = b.dyB; w.z = f.z_t1; w.z_bf16 = e.zb ? 1 : 0;
+        w.x = x; w.dy = b.dyB; w.W = P[EP_IT + TP_CONV1]; w.mode = 0;
         w.P1 = b.bn[BN_T1].P1; w.P2 = b.bn[BN_T1].P2; w.P3 = b.bn[BN_T1].P3;
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));

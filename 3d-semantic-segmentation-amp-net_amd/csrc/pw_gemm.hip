@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     const int n_rb = a.Q * a.chunks;
     const int cb0 = (within / 8) * CB;
     const bool perwin_w = a.w_win_stride != 0;
-    // Statistics per WORKGROUP (a.part_rows != nullptr; every layer but the pooled ones): lane = (slot, j) = (lane_id % n_slots,
+    // Statistics per WORKGROUP (a.part_rows != nullptr; the pooled layers too -- their per-(window, chunk) extremes keep their own slots): lane = (slot, j) = (lane_id % n_slots,
     // lane_id / n_slots) walks the blocks of rows j, j + L_slot, ... of ITS slot only (L_slot = the lanes that slot has: stat_lanes / n_slots,
     // one more for the first stat_lanes % n_slots slots), merges their (rows, mean, M2) as it goes and leaves ONE partial per column: ~57
     // partials per slot for bn_finalize (one stage) instead of one per block of rows (two stages) -- or none at all when a slot is a single
@@ -591,7 +591,9 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                 a.fin_suvar[o] = (float)(N > 1.0 ? m2 / (N - 1.0) : m2);
             }
         } else {
-            a.part_sum[(size_t)part_idx * a.cout + col] = (float)mean;
+            // pooled layers: the statistics were taken of z' = sgn(gamma) z -- the mean changes sign back, M2 does not care
+            const float sg = (POOL && a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
+            a.part_sum[(size_t)part_idx * a.cout + col] = sg * (float)mean;
             a.part_sq[(size_t)part_idx * a.cout + col] = (float)m2;
         }
     }
@@ -689,7 +691,7 @@ PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots)
 int pw_gemm(const PwGemm &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.A && a.W && (a.win_off || a.uniform_rows > 0), "pw_gemm: null pointer");
-    AMPNET_REQUIRE(!a.part_rows || (a.part_sum && !a.part_max && a.stat_lanes >= a.n_slots && a.stat_lanes <= 2048), "pw_gemm: per-workgroup statistics need part_sum, no pool epilogue and a lane plan");
+    AMPNET_REQUIRE(!a.part_rows || (a.part_sum && a.stat_lanes >= a.n_slots && a.stat_lanes <= 2048), "pw_gemm: per-workgroup statistics need part_sum and a lane plan");
     AMPNET_REQUIRE(!a.fin_scale || (a.part_rows && a.stat_lanes == a.n_slots && a.fin_gamma && a.fin_beta && a.fin_shift && cdiv(a.Q, a.n_slots) * a.chunks == 1),
                    "pw_gemm: in-kernel BatchNorm constants need one block of rows per slot");
     AMPNET_REQUIRE(a.Q >= 1 && a.chunks >= 1 && a.cout >= 1, "pw_gemm: bad sizes Q=%d chunks=%d cout=%d", a.Q, a.chunks, a.cout);

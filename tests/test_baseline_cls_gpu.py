@@ -173,7 +173,7 @@ def test_dropout_step_matches_float64_autograd(synth, tag, modname, pdim, base):
         noise = (sd32[k].grad.double() - w).norm().item()
         err = (p.grad.double().cpu().reshape(w.shape) - w).norm().item()
         worst = max(worst, err / (w.norm().item() + 1e-5 * gtot))
-        # everything under base_pointnet sits upstream of a max-pool over 256 points: when fp32 rounding moves ONE of the 16 x 256 (1024)
+        # everything under base_pointnet sits upstream of a max-pool over 256 points: when fp32 rounding moves ONE of the 16 x 256 (4096)
         # argmax rows to a near-tied neighbour the whole upstream gradient moves by ~1.6 % (tests/diagnostics/diag_baseline_noise.py: the same
         # step is 4.7e-5 from float64 with one summation order of the layer GEMMs and 2.5e-2 with another, the classifier head 3e-5 in both)
         floor = 6e-2 if k.startswith("base_pointnet.") else 2e-2
