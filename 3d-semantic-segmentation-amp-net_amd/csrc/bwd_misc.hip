@@ -668,10 +668,11 @@ int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
 // ----------------------------------------------------------------------------------------------------
 // input layers (K = 3 / 9): per-window dWeff[q][c][f] = sum_rows g[row][c] * x[row][f], lane = channel c
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
+constexpr int IW_WAVES = 8, IW_U = 16;     // waves per window, rows in flight per wave: the kernel is one pass over dy (HBM)
+__global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWgrad a)
 {
     __shared__ float sx[256 * 9];
-    __shared__ float red[4][64][9];
+    __shared__ float red[IW_WAVES][64][9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int row_begin = a.win_off[q], row_end = a.win_off[q + 1];
@@ -699,18 +700,18 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
     for (int base = row_begin; base < row_end; base += 256) {
         const int n = min(256, row_end - base);
         __syncthreads();
-        for (int e = tid; e < n * 9; e += 256) sx[e] = a.x[(size_t)base * 9 + e];
+        for (int e = tid; e < n * 9; e += 64 * IW_WAVES) sx[e] = a.x[(size_t)base * 9 + e];
         __syncthreads();
-        for (int i0 = wave; i0 < n; i0 += 32) {        // 8 rows per trip: 8 independent loads, then the FMAs
-            float dyv[8];
+        for (int i0 = wave; i0 < n; i0 += IW_WAVES * IW_U) {        // IW_U rows per trip: all loads first, then the FMAs
+            float dyv[IW_U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(i0 + 4 * u, n - 1);
+            for (int u = 0; u < IW_U; ++u) {
+                const int i = min(i0 + IW_WAVES * u, n - 1);
                 dyv[u] = a.dy[(size_t)(base + i) * 64 + lane];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 4 * u;
+            for (int u = 0; u < IW_U; ++u) {
+                const int i = i0 + IW_WAVES * u;
                 if (i < n) {
                     float z = 0.f;
                     if (three) {
@@ -732,7 +733,12 @@ __global__ __launch_bounds__(256) void pw_input_wgrad_kernel(PwInputWgrad a)
     if (wave == 0) {
 #pragma unroll
         for (int f = 0; f < 9; ++f)
-            a.dWeff[((size_t)q * 64 + lane) * 9 + f] = (red[0][lane][f] + red[1][lane][f]) + (red[2][lane][f] + red[3][lane][f]);
+        {
+            float v = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < IW_WAVES; ++w2) v += red[w2][lane][f];
+            a.dWeff[((size_t)q * 64 + lane) * 9 + f] = v;
+        }
     }
 }
 
@@ -740,7 +746,7 @@ int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.x && a.dy && a.W && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
     AMPNET_REQUIRE(a.mode == 0 || a.T, "pw_input_wgrad: mode 1 needs T");
-    hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(64 * IW_WAVES), 0, st, a);
     return check_launch("pw_input_wgrad_kernel");
 }
 

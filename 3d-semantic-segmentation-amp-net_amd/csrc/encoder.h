@@ -49,6 +49,9 @@ EncShape enc_shape(int Q, int n_slots, int R, int max_rows, int train);
 // the backward keeps two alternating regions of BatchNorm-backward partials in part_sum / part_sq: one per fused workgroup (<= 320 + n_slots)
 // + one per window (the scattered rows of the pooled layers), 256 channels wide
 inline size_t enc_bwd_part_region_floats(const EncShape &s) { return (size_t)(320 + s.n_slots + s.Q) * 256; }
+// the forward's per-workgroup statistics partials: <= 1024 lanes (pw_input) rounded up to whole slots, 256 channels wide, two regions
+inline size_t enc_fwd_part_region_rows(const EncShape &s) { return (size_t)1024 + 2 * (size_t)s.n_slots; }
+inline size_t enc_fwd_part_region_floats(const EncShape &s) { return enc_fwd_part_region_rows(s) * 256; }
 // carve the workspace; base may be nullptr to only compute ws.bytes
 void enc_carve(const EncShape &s, void *base, EncWs &ws);
 

@@ -89,12 +89,14 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.zext_t = c.take<float>(Q * 256);
     ws.zext_f = c.take<float>(Q * 256);
     ws.zext_c = c.take<float>(Q * 256);
-    ws.part_rows = c.take<int>(2048 + (size_t)s.n_slots);
+    ws.part_rows = c.take<int>(2 * enc_fwd_part_region_rows(s));
     ws.merge = c.take<float>(bn_finalize_merge_floats(s.n_slots, 256));     // two-stage bn_finalize scratch
     const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
     // the fused backward indexes its BatchNorm sums by workgroup (<= 256 + n_slots of them) + one row per window
     const size_t two_regions = 2 * enc_bwd_part_region_floats(s);
-    const size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256 > two_regions ? np + (size_t)(320 + s.n_slots) * 256 : two_regions;
+    size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256 > two_regions ? np + (size_t)(320 + s.n_slots) * 256 : two_regions;
+    // the forward alternates between two regions of per-workgroup statistics partials (a consumer merges its producer's while it writes its own)
+    if (np_bwd < 2 * enc_fwd_part_region_floats(s)) np_bwd = 2 * enc_fwd_part_region_floats(s);
     ws.part_sum = c.take<float>(np_bwd);
     ws.part_sq = c.take<float>(np_bwd);
     ws.part_max = c.take<float>(np);
@@ -128,6 +130,28 @@ struct EncRun {
     const int *win_off;
     BnParamRef bnp[BN_ENC_COUNT];
     bool zb = false;           // precision mode 3: the z tensors of the workspace are bf16
+    // BatchNorm statistics in flight: the producer of layer `bn` left `parts` per-workgroup partials in region `region` of part_sum / part_sq /
+    // part_rows; the next point layer merges them itself (PwGemm.pfin_*) or settle() launches bn_finalize.  Producers alternate regions.
+    struct Pending {
+        int bn = -1, parts = 0, region = 0;
+    };
+    mutable Pending pend;
+    mutable int region = 0;
+    float *psum(int r) const { return ws.part_sum + (size_t)r * enc_fwd_part_region_floats(s); }
+    float *psq(int r) const { return ws.part_sq + (size_t)r * enc_fwd_part_region_floats(s); }
+    int *prows(int r) const { return ws.part_rows + (size_t)r * enc_fwd_part_region_rows(s); }
+    bool consumer_fin() const
+    {
+        static const bool off = [] { const char *v = getenv("AMPNET_FWD_FIN_IN_KERNEL"); return v && v[0] == '0'; }();
+        return s.train && !off && !sync_bn_on();
+    }
+    void note_stats(int bn, int lanes) const
+    {
+        pend.bn = bn;
+        pend.parts = cdiv(lanes, s.n_slots) * s.n_slots;
+        pend.region = region;
+        region ^= 1;
+    }
 
     void bind_bn()
     {
@@ -156,14 +180,47 @@ struct EncRun {
         if (pro_bn >= 0) { g.pro_scale = ws.bn[pro_bn].scale; g.pro_shift = ws.bn[pro_bn].shift; }
         g.n_slots = s.train ? s.n_slots : 1;
         g.Z = Z; g.ldz = cout; g.cout = cout;
-        if (stats) { g.part_sum = ws.part_sum; g.part_sq = ws.part_sq; }
+        if (stats) { g.part_sum = psum(region); g.part_sq = psq(region); }
         if (pool) { g.part_max = ws.part_max; g.part_amax = ws.part_amax; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
         if (stats) {                                             // one partial per workgroup: bn_finalize in one stage (kernels.h)
-            g.part_rows = ws.part_rows;
+            g.part_rows = prows(region);
             g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots).lanes;
         }
+        if (stats && pro_bn >= 0 && pend.bn == pro_bn && consumer_fin() && (cin == 64 || cin == 128)) {
+            // this launch finishes its input's BatchNorm itself (kernels.h: pfin_*)
+            const BnSlot &b = ws.bn[pro_bn];
+            g.pfin_sum = psum(pend.region); g.pfin_sq = psq(pend.region); g.pfin_rows = prows(pend.region); g.pfin_parts = pend.parts;
+            g.pfin_gamma = bnp[pro_bn].gamma; g.pfin_beta = bnp[pro_bn].beta;
+            g.pfin_scale = b.scale; g.pfin_shift = b.shift; g.pfin_mean = b.mean; g.pfin_invstd = b.invstd; g.pfin_smean = b.smean; g.pfin_suvar = b.suvar;
+        }
         return g;
+    }
+    // launch a point layer: what is pending and not consumed by it is finalized first; its own statistics become the pending ones
+    int run_point(const PwGemm &g, int stats_bn) const
+    {
+        if (g.pfin_sum) pend.bn = -1;
+        else if (int rc = settle(); rc != AMPNET_OK) return rc;
+        if (int rc = pw_gemm(g, st); rc != AMPNET_OK) return rc;
+        if (stats_bn >= 0 && s.train) note_stats(stats_bn, g.stat_lanes);
+        return AMPNET_OK;
+    }
+    // the pending statistics through a bn_finalize launch (consumers that do not merge them themselves: the pool, eval-free paths)
+    int settle() const
+    {
+        if (pend.bn < 0 || !s.train) return AMPNET_OK;
+        const int bn = pend.bn;
+        pend.bn = -1;
+        BnFinalize f;
+        f.part_sum = psum(pend.region); f.part_sq = psq(pend.region); f.part_rows = prows(pend.region);
+        f.win_off = win_off;
+        f.Q = pend.parts; f.chunks = 1; f.chunk_rows = s.chunk_rows; f.uniform_rows = 0;
+        f.n_slots = s.n_slots; f.C = ws.bn[bn].C;
+        f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
+        f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;
+        f.stat_mean = ws.bn[bn].smean; f.stat_uvar = ws.bn[bn].suvar;
+        f.merge_ws = ws.merge;
+        return bn_finalize(f, st);
     }
     // FC layer on the pooled rows: n_slots windows of Q / n_slots rows (one window of Q rows in eval mode)
     // stats_bn >= 0: this layer's BatchNorm.  A slot's rows are one block of rows when fc_chunks == 1 (B <= 128): the workgroup then writes
@@ -189,25 +246,15 @@ struct EncRun {
         }
         return g;
     }
-    // wg: the producer left one partial per workgroup (point layers without pool, FC layers); otherwise one per (window, chunk)
-    // lanes: the producer left `lanes` per-workgroup partials (default: pw_gemm's plan); 0: one per (window, chunk) (the pooled layers)
-    int finalize(int bn, bool fc, int lanes = -1) const
+    // BatchNorm constants of an FC layer whose slot is more than one block of rows (B > 128); otherwise the GEMM wrote them itself
+    int finalize_fc(int bn) const
     {
-        if (!s.train) return AMPNET_OK;
-        if (fc && fc_direct()) return AMPNET_OK;                 // the FC GEMM wrote the constants itself
+        if (!s.train || fc_direct()) return AMPNET_OK;
         BnFinalize f;
-        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq;
+        f.part_sum = ws.part_sum; f.part_sq = ws.part_sq; f.part_rows = ws.part_rows;
         f.win_off = win_off;
-        f.Q = fc ? s.n_slots : s.Q;
-        f.chunks = fc ? s.fc_chunks : s.chunks;
-        f.chunk_rows = fc ? s.fc_chunk_rows : s.chunk_rows;
-        f.uniform_rows = fc ? s.fc_rows : ((long)s.max_rows * s.Q == (long)s.R ? s.max_rows : 0);
-        if (lanes != 0) {
-            f.part_rows = ws.part_rows;
-            f.Q = cdiv(lanes > 0 ? lanes : pw_gemm_stat_plan(f.Q, f.chunks, s.n_slots).lanes, s.n_slots) * s.n_slots;    // partial slots (kernels.h: PwStatPlan.parts)
-            f.chunks = 1;
-            f.uniform_rows = 0;
-        }
+        f.Q = cdiv(pw_gemm_stat_plan(s.n_slots, s.fc_chunks, s.n_slots).lanes, s.n_slots) * s.n_slots;    // partial slots (kernels.h: PwStatPlan.parts)
+        f.chunks = 1; f.chunk_rows = s.fc_chunk_rows; f.uniform_rows = 0;
         f.n_slots = s.n_slots; f.C = ws.bn[bn].C;
         f.gamma = bnp[bn].gamma; f.beta = bnp[bn].beta;
         f.scale = ws.bn[bn].scale; f.shift = ws.bn[bn].shift; f.mean = ws.bn[bn].mean; f.invstd = ws.bn[bn].invstd;
@@ -217,6 +264,7 @@ struct EncRun {
     }
     int pool(int bn, float *pooled, int *arg, float *zext, bool slot_major) const
     {
+        if (int rc = settle(); rc != AMPNET_OK) return rc;       // the pooled layer's own BatchNorm: nobody downstream merges it
         PoolFinalize p;
         p.part_max = ws.part_max; p.part_amax = ws.part_amax;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
@@ -241,25 +289,23 @@ int run_tnet(const EncRun &e, int pbase, int bn0, const float *x_or_A, int pro0,
     if (input_k3) {
         PwInput in;
         in.x = x_or_A; in.W = e.P[pbase + TP_CONV1]; in.mode = 0; in.Z = z1; in.z_bf16 = e.zb ? 1 : 0;
-        if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
+        TRY(e.settle());
+        if (tr) { in.part_sum = e.psum(e.region); in.part_sq = e.psq(e.region); }
         in.win_off = e.win_off; in.Q = e.s.Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
-        if (tr) { in.part_rows = e.ws.part_rows; in.stat_lanes = pw_input_stat_lanes(e.s.Q, e.s.chunks, e.s.n_slots); in.n_slots = e.s.n_slots; }
+        if (tr) { in.part_rows = e.prows(e.region); in.stat_lanes = pw_input_stat_lanes(e.s.Q, e.s.chunks, e.s.n_slots); in.n_slots = e.s.n_slots; }
         TRY(pw_input(in, e.st));
-        TRY(e.finalize(bn0 + 0, false, in.stat_lanes));
+        if (tr) e.note_stats(bn0 + 0, in.stat_lanes);
     } else {
-        TRY(pw_gemm(e.point_layer(x_or_A, 64, e.P[pbase + TP_CONV1], 64, pro0, z1, tr, false), e.st));
-        TRY(e.finalize(bn0 + 0, false));
+        TRY(e.run_point(e.point_layer(x_or_A, 64, e.P[pbase + TP_CONV1], 64, pro0, z1, tr, false), bn0 + 0));
     }
-    TRY(pw_gemm(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), e.st));
-    TRY(e.finalize(bn0 + 1, false));
-    TRY(pw_gemm(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true, bn0 + 2), e.st));
-    TRY(e.finalize(bn0 + 2, false));
+    TRY(e.run_point(e.point_layer(z1, 64, e.P[pbase + TP_CONV2], 128, bn0 + 0, z2, tr, false), bn0 + 1));
+    TRY(e.run_point(e.point_layer(z2, 128, e.P[pbase + TP_CONV3], 256, bn0 + 1, z3, tr, true, bn0 + 2), bn0 + 2));
     TRY(e.pool(bn0 + 2, pooled, arg, zext, true));
     // FC head on [Q, 256]
     TRY(pw_gemm(e.fc_layer(pooled, 256, e.P[pbase + TP_FC1], 256, nullptr, -1, zf1, 256, bn0 + 3), e.st));
-    TRY(e.finalize(bn0 + 3, true));
+    TRY(e.finalize_fc(bn0 + 3));
     TRY(pw_gemm(e.fc_layer(zf1, 256, e.P[pbase + TP_FC2], 128, nullptr, bn0 + 3, zf2, 128, bn0 + 4), e.st));
-    TRY(e.finalize(bn0 + 4, true));
+    TRY(e.finalize_fc(bn0 + 4));
     {
         PwGemm g = e.fc_layer(zf2, 128, e.P[pbase + TP_FC3_W], k * k, e.P[pbase + TP_FC3_B], bn0 + 4, T, k * k, -1);
         g.identity_k = k;                                        // + I (pointnetAtt.py:42-46) in the GEMM's bias, no extra launch
@@ -316,14 +362,14 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
         PwInput in;
         in.x = x; in.W = e.P[EP_CONV1]; in.T = e.ws.T3; in.mode = 1;
         in.perwin_slot_major = tr ? 1 : 0; in.n_slots = e.s.n_slots; in.Z = e.ws.z_c1; in.z_bf16 = e.zb ? 1 : 0;
-        if (tr) { in.part_sum = e.ws.part_sum; in.part_sq = e.ws.part_sq; }
+        TRY(e.settle());
+        if (tr) { in.part_sum = e.psum(e.region); in.part_sq = e.psq(e.region); }
         in.win_off = win_off; in.Q = Q; in.chunk_rows = e.s.chunk_rows; in.chunks = e.s.chunks;
-        if (tr) { in.part_rows = e.ws.part_rows; in.stat_lanes = pw_input_stat_lanes(Q, e.s.chunks, e.s.n_slots); }
+        if (tr) { in.part_rows = e.prows(e.region); in.stat_lanes = pw_input_stat_lanes(Q, e.s.chunks, e.s.n_slots); }
         TRY(pw_input(in, e.st));
-        TRY(e.finalize(BN_C1, false, in.stat_lanes));
+        if (tr) e.note_stats(BN_C1, in.stat_lanes);
     }
-    TRY(pw_gemm(e.point_layer(e.ws.z_c1, 64, e.P[EP_CONV2], 64, BN_C1, e.ws.z_c2, tr, false), e.st));
-    TRY(e.finalize(BN_C2, false));
+    TRY(e.run_point(e.point_layer(e.ws.z_c1, 64, e.P[EP_CONV2], 64, BN_C1, e.ws.z_c2, tr, false), BN_C2));
     // feature T-Net on relu(bn_2(z_c2))
     TRY(run_tnet(e, EP_FT, BN_F1, e.ws.z_c2, BN_C2, false, e.ws.z_f1, e.ws.z_f2, e.ws.z_f3, e.ws.pool_f, e.ws.arg_f, e.ws.zext_f, e.ws.z_ff1, e.ws.z_ff2, feat_T, 64));
     // local = relu(bn_2(z_c2)) x T64[window]  (torch.bmm, pointnetAtt.py:96)
@@ -331,16 +377,12 @@ extern "C" int ampnet_encoder_fwd_f32(const float *const *params_host, float *co
         PwGemm g = e.point_layer(e.ws.z_c2, 64, feat_T, 64, BN_C2, local, false, false, -1, true, false);     // local leaves as fp32
         g.w_win_stride = 64 * 64;
         g.perwin_slot_major = tr ? 1 : 0;
-        TRY(pw_gemm(g, e.st));
+        TRY(e.run_point(g, -1));
     }
-    TRY(pw_gemm(e.point_layer(local, 64, e.P[EP_CONV3], 64, -1, e.ws.z_c3, tr, false, -1, false, true), e.st));
-    TRY(e.finalize(BN_C3, false));
-    TRY(pw_gemm(e.point_layer(e.ws.z_c3, 64, e.P[EP_CONV4], 128, BN_C3, e.ws.z_c4, tr, false), e.st));
-    TRY(e.finalize(BN_C4, false));
-    TRY(pw_gemm(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), e.st));
-    TRY(e.finalize(BN_C5, false));
-    TRY(pw_gemm(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true, BN_C6), e.st));
-    TRY(e.finalize(BN_C6, false));
+    TRY(e.run_point(e.point_layer(local, 64, e.P[EP_CONV3], 64, -1, e.ws.z_c3, tr, false, -1, false, true), BN_C3));
+    TRY(e.run_point(e.point_layer(e.ws.z_c3, 64, e.P[EP_CONV4], 128, BN_C3, e.ws.z_c4, tr, false), BN_C4));
+    TRY(e.run_point(e.point_layer(e.ws.z_c4, 128, e.P[EP_CONV5], 128, BN_C4, e.ws.z_c5, tr, false), BN_C5));
+    TRY(e.run_point(e.point_layer(e.ws.z_c5, 128, e.P[EP_CONV6], 256, BN_C5, e.ws.z_c6, tr, true, BN_C6), BN_C6));
     TRY(e.pool(BN_C6, global_feat, e.ws.arg_c, e.ws.zext_c, false));
 
     if (tr) {

@@ -53,6 +53,16 @@ struct PwGemm {
     const float *fin_gamma = nullptr, *fin_beta = nullptr;
     float *fin_scale = nullptr, *fin_shift = nullptr, *fin_mean = nullptr, *fin_invstd = nullptr, *fin_smean = nullptr, *fin_suvar = nullptr;
     float fin_eps = 1e-5f;
+    // Consumer-side finalize of the INPUT's BatchNorm (train mode, per-workgroup statistics, PRO >= 1): instead of a bn_finalize launch
+    // between producer and consumer (~11 us of a mostly idle chip per layer), every workgroup of the consumer merges the producer's
+    // per-workgroup partials of ITS slot (pfin_parts / n_slots <= 114 partials of cin channels, out of L2) into the prologue constants it
+    // is about to stage; lane j == 0 of each slot (column block 0) also writes the arrays the backward, later consumers and the
+    // running-statistics update read.  The producer's partials must not be the buffers this launch writes its own partials to.
+    const float *pfin_sum = nullptr, *pfin_sq = nullptr;
+    const int *pfin_rows = nullptr;
+    int pfin_parts = 0;                       // partial slots (a multiple of n_slots; empty ones carry rows 0)
+    const float *pfin_gamma = nullptr, *pfin_beta = nullptr;
+    float *pfin_scale = nullptr, *pfin_shift = nullptr, *pfin_mean = nullptr, *pfin_invstd = nullptr, *pfin_smean = nullptr, *pfin_suvar = nullptr;
 };
 struct PwStatPlan {
     int lanes = 1;                 // workgroups that take part

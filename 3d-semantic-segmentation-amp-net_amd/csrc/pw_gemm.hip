@@ -142,6 +142,100 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     };
     if (!perwin_w) stage_weights(0);
 
+    int staged_slot = -1;
+    if (PRO && a.pfin_sum) {
+        // The input BatchNorm's constants of this workgroup's slot from the producer's per-workgroup partials (kernels.h: pfin_*), in ONE
+        // memory round trip: thread (gq, cq) takes the partials gq, gq + G, ... of the slot for the four channels 4 cq .. 4 cq + 3 (16-byte
+        // loads, all of a batch of eight in flight), sums n, n mean and M2 + n mean^2 in double, the groups of a wave are folded by
+        // shuffles and the waves through LDS in wave order: fixed order, bitwise reproducible.  M2 = sum (M2_i + n_i mean_i^2) - N mean^2 in
+        // double is exact to ~1e-10 of M2 for fp32 partials unless |mean| > 1e3 sigma.
+        constexpr int CQ = CIN / 4;                                    // channel quads
+        constexpr int GW = 64 / CQ >= 1 ? 64 / CQ : 1;                 // groups per wave (2 at 128 channels, 4 at 64)
+        constexpr int G = GW * PW_NW > 8 ? 8 : GW * PW_NW;             // groups in all
+        constexpr int WV = G / GW;                                     // waves that take part
+        static_assert(CQ <= 64 && G % GW == 0, "a wave holds whole groups");
+        double *rsm = reinterpret_cast<double *>(sRed);                // [WV][CIN] sum n mean, then [WV][CIN] sum (M2 + n mean^2), [WV] n
+        double *rsq = rsm + WV * CIN, *rnn = rsq + WV * CIN;
+        const int cq = lane % CQ, gq = wave * GW + lane / CQ;
+        const int per_slot_parts = a.pfin_parts / a.n_slots;
+        double sn = 0.0, sm[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (gq < G) {
+            for (int k0 = gq; k0 < per_slot_parts; k0 += G * 8) {
+                f32x4 v[8], w[8];
+                int rw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k0 + G * u;
+                    const int idx = my_slot + (kk < per_slot_parts ? kk : 0) * a.n_slots;
+                    rw[u] = kk < per_slot_parts ? a.pfin_rows[idx] : 0;
+                    v[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sum + (size_t)idx * CIN + 4 * cq);
+                    w[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sq + (size_t)idx * CIN + 4 * cq);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (rw[u] > 0) {
+                        const double nn = (double)rw[u];
+                        sn += nn;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const double m = (double)v[u][i];
+                            sm[i] += nn * m;
+                            sq[i] += (double)w[u][i] + nn * m * m;
+                        }
+                    }
+                }
+            }
+        }
+        // fold the groups of a wave (lanes cq, cq + CQ, ...), then the waves
+#pragma unroll
+        for (int off = CQ; off < 64; off <<= 1) {
+            sn += __shfl_xor(sn, off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sm[i] += __shfl_xor(sm[i], off);
+                sq[i] += __shfl_xor(sq[i], off);
+            }
+        }
+        if (wave < WV && lane < CQ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rsm[wave * CIN + 4 * cq + i] = sm[i];
+                rsq[wave * CIN + 4 * cq + i] = sq[i];
+            }
+            if (lane == 0) rnn[wave] = sn;
+        }
+        __syncthreads();
+        if (tid < CIN) {
+            const int c = tid;
+            double N = 0.0, S = 0.0, Q2 = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < WV; ++w2) {
+                N += rnn[w2];
+                S += rsm[w2 * CIN + c];
+                Q2 += rsq[w2 * CIN + c];
+            }
+            const double mean = N > 0.0 ? S / N : 0.0;
+            double m2 = Q2 - N * mean * mean;
+            if (m2 < 0.0) m2 = 0.0;
+            const double var = N > 0.0 ? m2 / N : 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)a.fin_eps));
+            const float sc = a.pfin_gamma[c] * invstd;
+            const float sh = a.pfin_beta[c] - (float)mean * sc;
+            sPro[c] = sc;
+            sPro[CIN + c] = sh;
+            if (sl.j == 0 && cb0 == 0) {                        // one writer per slot
+                const size_t o = (size_t)my_slot * CIN + c;
+                a.pfin_scale[o] = sc;
+                a.pfin_shift[o] = sh;
+                a.pfin_mean[o] = (float)mean;
+                a.pfin_invstd[o] = invstd;
+                a.pfin_smean[o] = (float)mean;
+                a.pfin_suvar[o] = (float)(N > 1.0 ? m2 / (N - 1.0) : m2);
+            }
+        }
+        staged_slot = my_slot;
+        __syncthreads();                                        // sRed is free again, sPro is staged
+    }
     const uint32_t dthr = drop_threshold(a.drop_p);
     const uint32_t dbase = a.drop_seed;
     const float dscale = PRO == 2 ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -154,7 +248,6 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         const int col = cb0 + 32 * t + r;
         sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
     }
-    int staged_slot = -1;
   const int it_end = wg_stats ? slot_items : n_rb, it_step = wg_stats ? slot_lanes : n_lanes;
   for (int it = wg_stats ? sl.j : lane_id; it < it_end; it += it_step) {
     const int q = wg_stats ? my_slot + (it / a.chunks) * a.n_slots : it / a.chunks;
@@ -609,7 +702,9 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
     constexpr size_t lds_main = BF ? (size_t)CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
-    constexpr size_t lds_red = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float) + (size_t)CB * 2 * sizeof(double);   // + sRun
+    constexpr size_t lds_red0 = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float) + (size_t)CB * 2 * sizeof(double);   // + sRun
+    constexpr size_t lds_pfin = (size_t)(4 * 2 * CIN + 8) * sizeof(double);                   // scratch of the consumer-side BatchNorm finalize (same region)
+    constexpr size_t lds_red = lds_red0 > lds_pfin ? lds_red0 : lds_pfin;
     constexpr size_t lds = lds_main + lds_red;
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
     auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE>;
@@ -692,6 +787,10 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
 {
     AMPNET_REQUIRE(a.A && a.W && (a.win_off || a.uniform_rows > 0), "pw_gemm: null pointer");
     AMPNET_REQUIRE(!a.part_rows || (a.part_sum && a.stat_lanes >= a.n_slots && a.stat_lanes <= 2048), "pw_gemm: per-workgroup statistics need part_sum and a lane plan");
+    AMPNET_REQUIRE(!a.pfin_sum || (a.part_rows && a.pro_scale && a.pfin_sq && a.pfin_rows && a.pfin_parts >= a.n_slots && a.pfin_parts % a.n_slots == 0 && a.pfin_gamma &&
+                                   a.pfin_beta && a.pfin_scale && a.pfin_shift && a.pfin_mean && a.pfin_invstd && a.pfin_smean && a.pfin_suvar && a.pfin_sum != a.part_sum &&
+                                   a.pfin_rows != a.part_rows && (a.cin == 64 || a.cin == 128) && !a.w_win_stride && a.pfin_parts / a.n_slots <= 1024),
+                   "pw_gemm: consumer-side BatchNorm finalize needs per-workgroup statistics, the producer's partials in buffers of their own and every output array");
     AMPNET_REQUIRE(!a.fin_scale || (a.part_rows && a.stat_lanes == a.n_slots && a.fin_gamma && a.fin_beta && a.fin_shift && cdiv(a.Q, a.n_slots) * a.chunks == 1),
                    "pw_gemm: in-kernel BatchNorm constants need one block of rows per slot");
     AMPNET_REQUIRE(a.Q >= 1 && a.chunks >= 1 && a.cout >= 1, "pw_gemm: bad sizes Q=%d chunks=%d cout=%d", a.Q, a.chunks, a.cout);
