@@ -12,13 +12,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void posenc_tokens_kernel(const float *__restrict__ gl, const float *__restrict__ cent,
                                                            const float *__restrict__ w1, const float *__restrict__ b1,
                                                            const float *__restrict__ w2, const float *__restrict__ b2,
-                                                           float *__restrict__ tok)
+                                                           float *__restrict__ tok, float *__restrict__ hid_out, float *__restrict__ slope_out)
 {
     __shared__ float hid[16];
     const int q = blockIdx.x, e = threadIdx.x;
     if (e < 16) {
         const float v = fmaf(cent[q * 2 + 1], w1[e * 2 + 1], fmaf(cent[q * 2 + 0], w1[e * 2 + 0], b1[e]));
         hid[e] = v > 0.f ? v : 0.01f * v;                        // F.leaky_relu_, slope 0.01
+        if (hid_out) {                                           // train mode: what the backward of the two Linear layers needs
+            hid_out[q * 16 + e] = hid[e];
+            slope_out[q * 16 + e] = v > 0.f ? 1.0f : 0.01f;
+        }
     }
     __syncthreads();
     float acc = b2[e];
@@ -28,9 +32,9 @@ __global__ __launch_bounds__(256) void posenc_tokens_kernel(const float *__restr
 }
 
 int posenc_tokens(const float *gl, const float *cent, const float *w1, const float *b1, const float *w2, const float *b2,
-                  float *tok, int Q, hipStream_t st)
+                  float *tok, int Q, hipStream_t st, float *hid_out, float *slope_out)
 {
-    hipLaunchKernelGGL(posenc_tokens_kernel, dim3(Q), dim3(HEAD_E), 0, st, gl, cent, w1, b1, w2, b2, tok);
+    hipLaunchKernelGGL(posenc_tokens_kernel, dim3(Q), dim3(HEAD_E), 0, st, gl, cent, w1, b1, w2, b2, tok, hid_out, slope_out);
     return check_launch("posenc_tokens_kernel");
 }
 

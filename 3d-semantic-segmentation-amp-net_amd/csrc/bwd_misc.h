@@ -19,6 +19,12 @@ struct PwInputWgrad {
     // read back: the kernel sits on HBM, and z was half of its bytes
     const float *W = nullptr, *T = nullptr;   // as PwInput: mode 0 W [64, 3]; mode 1 W [64, 12], T [.., 3, 3] per window
     int mode = 0, perwin_slot_major = 0;
+    // optional: this layer's BatchNorm-backward constants formed in the kernel from the partial sums its producer left (as PwBwd.fin_*,
+    // kernels.h); the first window of each slot also writes P1 / P2 / P3 / slot_ab for bn_param_grads
+    const float *fin_part_a = nullptr, *fin_part_b = nullptr;
+    int fin_parts = 0, fin_rows = 0;
+    const float *fin_gamma = nullptr, *fin_mean = nullptr, *fin_invstd = nullptr;
+    float *fin_P1 = nullptr, *fin_P2 = nullptr, *fin_P3 = nullptr, *fin_slot_ab = nullptr;
     const float *P1 = nullptr, *P2 = nullptr, *P3 = nullptr;   // [n_slots, 64]
     float *dWeff = nullptr;                   // [Q, 64, 9]
     const int *win_off = nullptr;

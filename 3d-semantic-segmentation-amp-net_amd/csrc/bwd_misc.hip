@@ -217,6 +217,7 @@ struct SgProblem {
     int M, N, K, ta, tb, lda, ldb, ldc, accumulate;
     const float *A, *B;
     float *C;
+    const float *mul = nullptr;        // [M, N] with leading dimension ldc: C = (product) * mul elementwise (sgemm_mfma only)
     float *db = nullptr;               // [M]: row sums of op(A) over K (the bias gradient G^T 1 of a weight-gradient problem), taken by the
                                        // workgroups of the first column of tiles from the A tile they stage anyway: no extra problem, no extra launch
 };
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(64 * SGM_WAVES) void sgemm_mfma_kernel(SgArgs args)
         for (int w = 0; w < SGM_WAVES; ++w) v += red[w][e][lane];
         if (gm < M && gn < N) {
             float *d = g.C + (size_t)gm * g.ldc + gn;
+            if (g.mul) v *= g.mul[(size_t)gm * g.ldc + gn];
             *d = g.accumulate ? *d + v : v;
         }
     }
@@ -447,7 +449,9 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
     }
     if (n == 1) a.p[1] = a.p[0];
     // AMPNET_SGEMM_VALU=1: the VALU kernel (A/B timing, tests/test_small_gemm_gpu.py compares the two)
-    static const bool valu = [] { const char *e = getenv("AMPNET_SGEMM_VALU"); return e && e[0] == '1'; }();
+    static const bool valu_env = [] { const char *e = getenv("AMPNET_SGEMM_VALU"); return e && e[0] == '1'; }();
+    bool valu = valu_env;
+    for (int i = 0; i < n; ++i) valu = valu && !probs[i].mul;          // the multiply epilogue lives in the matrix-core kernel only
     if (valu) {
         ProfScope prof("sgemm_small", flops, bytes, st);
         hipLaunchKernelGGL(sgemm_small_kernel, dim3(gx, gy, n), dim3(256 * SG_SK), 0, st, a);
@@ -489,6 +493,7 @@ int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, con
     p[0] = {n_out, n_in, rows, 1, 0, ldg, ldx, lddw, 0, G, X, dW};
     p[0].db = o.db;
     p[1] = {rows, n_in, n_out, 0, 0, ldg, ldw, lddx, 0, G, W, dX};
+    p[1].mul = o.dx_mul;
     return sgemm_launch(p, 2, st);
 }
 
@@ -672,12 +677,63 @@ constexpr int IW_WAVES = 8, IW_U = 16;     // waves per window, rows in flight p
 __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWgrad a)
 {
     __shared__ float sx[256 * 9];
-    __shared__ float red[IW_WAVES][64][9];
+    __shared__ __attribute__((aligned(16))) float red[IW_WAVES][64][9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int row_begin = a.win_off[q], row_end = a.win_off[q + 1];
     const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
-    const float p1 = a.P1[(size_t)slot * 64 + lane], p2 = a.P2[(size_t)slot * 64 + lane], p3 = a.P3[(size_t)slot * 64 + lane];
+    float p1, p2, p3;
+    if (a.fin_part_a) {
+        // wave w sums the slot's partials w, w + IW_WAVES, ... (all loads of a trip in flight), the waves merge through LDS in wave order
+        double sa = 0.0, sb = 0.0;
+        const int per_slot_parts = (a.fin_parts - slot + a.n_slots - 1) / a.n_slots;
+        for (int k0 = wave; k0 < per_slot_parts; k0 += IW_WAVES * 8) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + IW_WAVES * u;
+                const size_t o = (size_t)(slot + (k < per_slot_parts ? k : 0) * a.n_slots) * 64 + lane;
+                va[u] = a.fin_part_a[o];
+                vb[u] = a.fin_part_b[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + IW_WAVES * u < per_slot_parts) {
+                    sa += (double)va[u];
+                    sb += (double)vb[u];
+                }
+            }
+        }
+        double *fr = reinterpret_cast<double *>(&red[0][0][0]);       // [IW_WAVES][64][2]
+        fr[(wave * 64 + lane) * 2 + 0] = sa;
+        fr[(wave * 64 + lane) * 2 + 1] = sb;
+        __syncthreads();
+        double A = 0.0, Bs = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < IW_WAVES; ++w2) {
+            A += fr[(w2 * 64 + lane) * 2 + 0];
+            Bs += fr[(w2 * 64 + lane) * 2 + 1];
+        }
+        __syncthreads();                                               // red[] is reused below
+        const size_t o = (size_t)slot * 64 + lane;
+        const double n = (double)a.fin_rows, invstd = a.fin_invstd[o], mean = a.fin_mean[o];
+        const double s = (double)a.fin_gamma[lane] * invstd;
+        const double q2 = -s * invstd * Bs / n;
+        p1 = (float)s;
+        p2 = (float)q2;
+        p3 = (float)(-s * A / n - q2 * mean);
+        if (q < a.n_slots && wave == 0) {                              // the first window of each slot: the arrays other kernels read
+            a.fin_slot_ab[o * 2 + 0] = (float)A;
+            a.fin_slot_ab[o * 2 + 1] = (float)Bs;
+            a.fin_P1[o] = p1;
+            a.fin_P2[o] = p2;
+            a.fin_P3[o] = p3;
+        }
+    } else {
+        p1 = a.P1[(size_t)slot * 64 + lane];
+        p2 = a.P2[(size_t)slot * 64 + lane];
+        p3 = a.P3[(size_t)slot * 64 + lane];
+    }
     // effective weights of this lane's channel, exactly as pw_input forms them (pw_misc.hip)
     float w[9];
     if (a.mode == 0) {
@@ -744,7 +800,10 @@ __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWg
 
 int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.x && a.dy && a.W && a.P1 && a.P2 && a.P3 && a.dWeff && a.win_off, "pw_input_wgrad: null pointer");
+    AMPNET_REQUIRE(a.x && a.dy && a.W && a.dWeff && a.win_off && (a.fin_part_a || (a.P1 && a.P2 && a.P3)), "pw_input_wgrad: null pointer");
+    AMPNET_REQUIRE(!a.fin_part_a || (a.fin_part_b && a.fin_parts >= a.n_slots && a.fin_rows >= 1 && a.fin_gamma && a.fin_mean && a.fin_invstd && a.fin_P1 && a.fin_P2 && a.fin_P3 &&
+                                     a.fin_slot_ab && a.Q >= a.n_slots),
+                   "pw_input_wgrad: in-kernel BatchNorm-backward constants need the producer's partials, the layer's statistics and the output arrays");
     AMPNET_REQUIRE(a.mode == 0 || a.T, "pw_input_wgrad: mode 1 needs T");
     hipLaunchKernelGGL(pw_input_wgrad_kernel, dim3(a.Q), dim3(64 * IW_WAVES), 0, st, a);
     return check_launch("pw_input_wgrad_kernel");

@@ -264,8 +264,14 @@ struct EncRun {
     }
     int pool(int bn, float *pooled, int *arg, float *zext, bool slot_major) const
     {
-        if (int rc = settle(); rc != AMPNET_OK) return rc;       // the pooled layer's own BatchNorm: nobody downstream merges it
         PoolFinalize p;
+        if (pend.bn == bn && consumer_fin() && ws.bn[bn].C == 256) {             // the pooled layer's own BatchNorm, finished by this launch
+            const BnSlot &bs = ws.bn[bn];
+            p.pfin_sum = psum(pend.region); p.pfin_sq = psq(pend.region); p.pfin_rows = prows(pend.region); p.pfin_parts = pend.parts;
+            p.pfin_gamma = bnp[bn].gamma; p.pfin_beta = bnp[bn].beta;
+            p.pfin_scale = bs.scale; p.pfin_shift = bs.shift; p.pfin_mean = bs.mean; p.pfin_invstd = bs.invstd; p.pfin_smean = bs.smean; p.pfin_suvar = bs.suvar;
+            pend.bn = -1;
+        } else if (int rc = settle(); rc != AMPNET_OK) return rc;
         p.part_max = ws.part_max; p.part_amax = ws.part_amax;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
         p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;

@@ -11,6 +11,30 @@
 #include "encoder.h"
 
 namespace ampnet {
+// [32, 64] ones and zeros: the "BatchNorm-backward constants" of a gradient that is passed through as it is (g = dy: the fused bmm backward).
+// Device globals filled once per device and process instead of once per step (a 5 us launch).
+__device__ float g_ident_ones[32 * 64];
+__device__ float g_ident_zeros[32 * 64];
+static int identity_constants(int n_slots, const float **ones, const float **zeros, hipStream_t st)
+{
+    AMPNET_REQUIRE(n_slots <= 32, "identity_constants: %d slots", n_slots);
+    static bool ready[64] = {};
+    int dev = 0;
+    float *po = nullptr, *pz = nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || hipGetSymbolAddress(reinterpret_cast<void **>(&po), HIP_SYMBOL(g_ident_ones)) != hipSuccess ||
+        hipGetSymbolAddress(reinterpret_cast<void **>(&pz), HIP_SYMBOL(g_ident_zeros)) != hipSuccess)
+        return fail(AMPNET_E_LAUNCH, "identity_constants: device symbol lookup failed");
+    if (!ready[dev]) {
+        int rc = fill_f32_pair(po, 1.0f, pz, 0.0f, (size_t)32 * 64, st);
+        if (rc != AMPNET_OK) return rc;
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(AMPNET_E_LAUNCH, "identity_constants: synchronize failed");
+        ready[dev] = true;
+    }
+    *ones = po;
+    *zeros = pz;
+    return AMPNET_OK;
+}
+
 namespace {
 
 struct BnBwdSlot {
@@ -143,6 +167,19 @@ struct EncBwd {
         fz.gamma = gamma[bn]; fz.mean = f.bn[bn].mean; fz.invstd = f.bn[bn].invstd;
         fz.P1 = b.bn[bn].P1; fz.P2 = b.bn[bn].P2; fz.P3 = b.bn[bn].P3; fz.slot_ab = b.bn[bn].slot_ab;
         return bn_bwd_finalize(fz, st);
+    }
+    // the input layers' weight-gradient kernel as consumer of an owed finalize (bwd_misc.h: PwInputWgrad.fin_*)
+    int input_fin(PwInputWgrad &w, int bn) const
+    {
+        if (owed.open && in_kernel_fin && owed.bn == bn && owed.chunks == 1 && owed.C == 64) {
+            w.fin_part_a = owed.pa; w.fin_part_b = owed.pb; w.fin_parts = owed.parts;
+            w.fin_rows = (s.Q / s.n_slots) * s.max_rows;
+            w.fin_gamma = gamma[bn]; w.fin_mean = f.bn[bn].mean; w.fin_invstd = f.bn[bn].invstd;
+            w.fin_P1 = b.bn[bn].P1; w.fin_P2 = b.bn[bn].P2; w.fin_P3 = b.bn[bn].P3; w.fin_slot_ab = b.bn[bn].slot_ab;
+            owed.open = false;
+            return AMPNET_OK;
+        }
+        return settle();
     }
     int flush_deferred() const
     {
@@ -478,9 +515,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
             // d_h[row][k] = sum_j d_local[row][j] T[k][j] (masked by conv_2's ReLU here already: the mask is idempotent and the
             // feature T-Net's conv_1 backward applies it again after adding its own term).  g = dy via identity constants.
             TRY(e.settle());
-            TRY(fill_f32_pair(b.ones64, 1.0f, b.zeros64, 0.0f, (size_t)n_slots * 64, st));
+            const float *ones64 = nullptr, *zeros64 = nullptr;
+            TRY(identity_constants(n_slots, &ones64, &zeros64, st));
             PwBwd p;
-            p.g.dy = b.d_local; p.g.z = b.d_local; p.g.C = 64; p.g.P1 = b.ones64; p.g.P2 = b.zeros64; p.g.P3 = b.zeros64;
+            p.g.dy = b.d_local; p.g.z = b.d_local; p.g.C = 64; p.g.P1 = ones64; p.g.P2 = zeros64; p.g.P3 = zeros64;
             p.prev = e.act(f.z_c2, BN_C2, 64);
             p.W = feat_T; p.ldw = 64; p.w_win_stride = 4096; p.perwin_slot_major = 1;
             p.out = b.d_h; p.dWpart = b.dT64t;
@@ -523,10 +561,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(e.layer_bwd(g, P[EP_CONV2], G[EP_CONV2], f.z_c1, BN_C1, 64, nullptr, b.dyB));
     }
     {
-        TRY(e.settle());                       // pw_input_wgrad reads bn_1's constants from memory
         PwInputWgrad w;
         w.x = x; w.dy = b.dyB; w.W = P[EP_CONV1]; w.T = f.T3; w.mode = 1; w.perwin_slot_major = 1;
         w.P1 = b.bn[BN_C1].P1; w.P2 = b.bn[BN_C1].P2; w.P3 = b.bn[BN_C1].P3;
+        TRY(e.input_fin(w, BN_C1));            // bn_1's constants: in the kernel when they are still owed, else from memory
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));
         TRY(input_param_grads(b.dWeff, P[EP_CONV1], f.T3, Q, n_slots, 1, 1, G[EP_CONV1], b.dT3, st));
@@ -539,10 +577,10 @@ extern "C" int ampnet_encoder_bwd_f32(const float *const *params_host, float *co
         TRY(e.layer_bwd(g, P[EP_IT + TP_CONV2], G[EP_IT + TP_CONV2], f.z_t1, BN_T1, 64, nullptr, b.dyB));
     }
     {
-        TRY(e.settle());
         PwInputWgrad w;
         w.x = x; w.dy = b.dyB; w.W = P[EP_IT + TP_CONV1]; w.mode = 0;
         w.P1 = b.bn[BN_T1].P1; w.P2 = b.bn[BN_T1].P2; w.P3 = b.bn[BN_T1].P3;
+        TRY(e.input_fin(w, BN_T1));
         w.dWeff = b.dWeff; w.win_off = win_off; w.Q = Q; w.n_slots = n_slots;
         TRY(pw_input_wgrad(w, st));
         TRY(input_param_grads(b.dWeff, P[EP_IT + TP_CONV1], nullptr, Q, n_slots, 0, 0, G[EP_IT + TP_CONV1], nullptr, st));

@@ -31,6 +31,7 @@ struct BnSlot1 {
 struct HeadWs {
     // attention: tok [Q,256] qkv [Q,768] probs [B,8,W,W] ctx [Q,256] g2 [Q,256] (out_proj output = the token)
     // GRU:       qkv = gi [Q,192] (W_ih x + b_ih), ctx = gates [Q,4,64] (r, z, n, W_hn h + b_hn), g2 = h [Q,64]; tok / probs unused
+    float *pe_hid, *pe_slope;                      // [Q,16] hidden layer of the positional encoding and its leaky-ReLU slope (attention, for the backward)
     float *tok, *qkv, *probs, *ctx, *g2, *gbias;   // gbias [Q,128]: token half of conv_2 + its bias, one row per window
     float *z2, *z3;                                // [R,128] [R,64]
     int *part_rows;                                // [1024] rows per per-workgroup statistics partial (PwGemm.part_rows)
@@ -90,7 +91,7 @@ int head_points_bwd(const HeadShape &s, HeadWs &f, HeadBwdWs &b, const HeadPoint
 
 // tok[q, :] = gl[q, :] + fc2(leaky_relu(fc1(centroids[q, :])))     (pointnetAtt.py:183-185)
 int posenc_tokens(const float *gl, const float *cent, const float *w1, const float *b1, const float *w2, const float *b2,
-                  float *tok, int Q, hipStream_t st);
+                  float *tok, int Q, hipStream_t st, float *hid_out = nullptr, float *slope_out = nullptr);
 // softmax(q k^T / sqrt(d) + mask) [dropout] v per (sample, head)      (nn.MultiheadAttention core)
 int attention_core(const float *qkv, const uint8_t *key_pad_mask, float *probs, float *ctx, int B, int W, float drop_p,
                    uint32_t drop_base, hipStream_t st);

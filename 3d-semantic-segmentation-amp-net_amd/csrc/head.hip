@@ -64,6 +64,8 @@ void head_carve(const HeadShape &s, void *base, HeadWs &ws)
     const size_t Q = (size_t)s.Q, R = (size_t)s.R;
     const bool gru = s.kind == HEAD_KIND_GRU;
     ws.tok = c.take<float>(gru ? 0 : Q * 256);
+    ws.pe_hid = c.take<float>(gru ? 0 : Q * 16);
+    ws.pe_slope = c.take<float>(gru ? 0 : Q * 16);
     ws.qkv = c.take<float>(Q * (gru ? 3 * GRU_H : 768));
     ws.probs = c.take<float>(gru ? 0 : (size_t)s.B * HEAD_HEADS * s.W * s.W);
     ws.ctx = c.take<float>(Q * 256);
@@ -205,7 +207,7 @@ static int head_fwd_impl(const float *const *params_host, float *const *buffers_
     const int Q = s.Q;
     if (tr) ws_tag_set(workspace, matrix_precision());
 
-    TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st));
+    TRY(posenc_tokens(gl, centroids, P[HP_FC1_W], P[HP_FC1_B], P[HP_FC2_W], P[HP_FC2_B], ws.tok, Q, st, s.train ? ws.pe_hid : nullptr, s.train ? ws.pe_slope : nullptr));
     auto tok_gemm = [&](const float *A, const float *Wm, int ldw, const float *bias, int cout, float *Z) {
         PwGemm g;
         g.A = A; g.lda = 256; g.cin = 256;

@@ -187,23 +187,6 @@ __global__ __launch_bounds__(64) void attention_core_bwd_kernel(const float *__r
 }
 
 // positional encoding backward: hidden activations recomputed per token
-__global__ __launch_bounds__(64) void posenc_hidden_kernel(const float *__restrict__ cent, const float *__restrict__ w1,
-                                                          const float *__restrict__ b1, int Q, float *__restrict__ hid, float *__restrict__ slope)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= Q * 16) return;
-    const int q = i / 16, e = i % 16;
-    const float v = fmaf(cent[q * 2 + 1], w1[e * 2 + 1], fmaf(cent[q * 2 + 0], w1[e * 2 + 0], b1[e]));
-    hid[i] = v > 0.f ? v : 0.01f * v;
-    slope[i] = v > 0.f ? 1.0f : 0.01f;
-}
-
-__global__ void mul_inplace_kernel(float *__restrict__ x, const float *__restrict__ y, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] *= y[i];
-}
-
 }  // namespace
 }  // namespace ampnet
 
@@ -484,15 +467,13 @@ extern "C" int ampnet_head_bwd_f32(const float *const *params_host, float *const
         TRY(sgemm_linear_bwd(Q, 768, 256, b.d_qkv, 768, f.tok, 256, P[HP_INPROJ_W], 256, G[HP_INPROJ_W], 256, d_gl, 256, st, o));   // d_tok = d_gl = d_pos
     }
     // ---- positional encoding: pos = leaky(cent W1^T + b1) W2^T + b2 --------------------------------------------
-    hipLaunchKernelGGL(posenc_hidden_kernel, dim3(cdiv(Q * 16, 64)), dim3(64), 0, st, centroids, P[HP_FC1_W], P[HP_FC1_B], Q, b.hid, b.slope);
-    TRY(check_launch("posenc_hidden_kernel"));
+    // the hidden layer and its leaky-ReLU slope were kept by the forward (HeadWs.pe_*); the slope multiplies the data gradient as it is written
     {
         LinBwdOpt o;
         o.db = G[HP_FC2_B];
-        TRY(sgemm_linear_bwd(Q, 256, 16, d_gl, 256, b.hid, 16, P[HP_FC2_W], 16, G[HP_FC2_W], 16, b.d_hid, 16, st, o));
+        o.dx_mul = f.pe_slope;
+        TRY(sgemm_linear_bwd(Q, 256, 16, d_gl, 256, f.pe_hid, 16, P[HP_FC2_W], 16, G[HP_FC2_W], 16, b.d_hid, 16, st, o));
     }
-    hipLaunchKernelGGL(mul_inplace_kernel, dim3(cdiv(Q * 16, 256)), dim3(256), 0, st, b.d_hid, b.slope, Q * 16);
-    TRY(check_launch("mul_inplace_kernel"));
     TRY(sgemm_wgrad_bias(Q, 16, 2, b.d_hid, 16, centroids, 2, G[HP_FC1_W], 2, G[HP_FC1_B], st));
     return AMPNET_OK;
 }

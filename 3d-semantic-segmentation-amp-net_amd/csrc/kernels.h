@@ -192,6 +192,14 @@ struct PoolFinalize {
     float *pooled = nullptr;      // [Q, C]
     int *arg = nullptr;           // [Q, C] or nullptr
     float *zext = nullptr;        // [Q, C] or nullptr: the pre-BatchNorm extreme itself (row q)
+    // train mode, C == 256: the pooled layer's BatchNorm is finished HERE from the per-workgroup partials of the layer's GEMM (as
+    // PwGemm.pfin_*: no bn_finalize launch in between); scale / shift above are then OUTPUTS like the other arrays
+    const float *pfin_sum = nullptr, *pfin_sq = nullptr;
+    const int *pfin_rows = nullptr;
+    int pfin_parts = 0;
+    const float *pfin_gamma = nullptr, *pfin_beta = nullptr;
+    float pfin_eps = 1e-5f;
+    float *pfin_scale = nullptr, *pfin_shift = nullptr, *pfin_mean = nullptr, *pfin_invstd = nullptr, *pfin_smean = nullptr, *pfin_suvar = nullptr;
 };
 int pool_finalize(const PoolFinalize &a, hipStream_t st);
 
@@ -452,6 +460,8 @@ int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int
 // backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W
 struct LinBwdOpt {
     float *db = nullptr;                         // [n_out]: the bias gradient (column sums of G), taken inside the weight-gradient problem
+    const float *dx_mul = nullptr;               // [rows, n_in] (same leading dimension as dX): dX is multiplied elementwise as it is written
+                                                 // (the derivative of the activation in front of the layer)
 };
 int sgemm_linear_bwd(int rows, int n_out, int n_in, const float *G, int ldg, const float *X, int ldx, const float *W, int ldw, float *dW, int lddw,
                      float *dX, int lddx, hipStream_t st, const LinBwdOpt &o = LinBwdOpt());

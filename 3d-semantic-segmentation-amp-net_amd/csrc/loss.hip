@@ -40,11 +40,20 @@ __global__ void reg_finalize_kernel(const float *__restrict__ part, int n, float
 }
 
 // dF += coef * d(reg)/dF,  d(reg)/dF = -2 G F / reg   (G symmetric)
+// lead > 0: dF is a stack of lead + n matrices that is WRITTEN: zeros in the first `lead` (the windows the regulariser does not see), the
+// gradient itself in the last n (no accumulate): the caller then needs no zero fill of the stack (9.4 MB and a launch per step)
 __global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ F, const float *__restrict__ G,
-                                                     const float *__restrict__ reg, float coef, float *__restrict__ dF)
+                                                     const float *__restrict__ reg, float coef, float *__restrict__ dF, int lead, int write)
 {
     __shared__ float sF[64][65], sG[64][65];
-    const int m = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < lead) {
+        float4 *z = reinterpret_cast<float4 *>(dF + (size_t)blockIdx.x * 4096);
+        for (int e = tid; e < 1024; e += 256) z[e] = float4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int m = (int)blockIdx.x - lead;
+    dF += (size_t)lead * 4096;
     for (int e = tid; e < 4096; e += 256) {
         sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
         sG[e / 64][e % 64] = G[(size_t)m * 4096 + e];
@@ -57,7 +66,8 @@ __global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ 
         float d = 0.f;
 #pragma unroll 8
         for (int l = 0; l < 64; ++l) d = fmaf(sG[i][l], sF[l][j], d);
-        dF[(size_t)m * 4096 + e] += k * d;
+        if (write) dF[(size_t)m * 4096 + e] = k * d;
+        else dF[(size_t)m * 4096 + e] += k * d;
     }
 }
 
@@ -104,8 +114,16 @@ extern "C" int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, cons
                                        void *stream)
 {
     AMPNET_REQUIRE(feat_T && G && reg && d_feat_T && n >= 1, "ampnet_reg_loss_bwd_f32: bad arguments");
-    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T);
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T, 0, 0);
     return check_launch("reg_loss_bwd");
+}
+
+extern "C" int ampnet_reg_loss_bwd_stack_f32(const float *feat_T, const float *G, const float *reg, float coef, int n, int n_total, float *d_feat_T_stack,
+                                             void *stream)
+{
+    AMPNET_REQUIRE(feat_T && G && reg && d_feat_T_stack && n >= 1 && n_total >= n, "ampnet_reg_loss_bwd_stack_f32: bad arguments");
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n_total), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T_stack, n_total - n, 1);
+    return check_launch("reg_loss_bwd_stack");
 }
 
 extern "C" int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,

@@ -397,10 +397,95 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
     }
 }
 
+// The same with the layer's BatchNorm finished in the kernel (PoolFinalize.pfin_*): workgroup = (slot, four windows of it), 1024 threads =
+// 4 groups x 256 channels.  Group g first sums the slot's partials g, g + 4, ... (n, n mean, M2 + n mean^2 in double, sixteen partials in
+// flight per thread: one memory round trip for the ~57 a slot has), the groups merge through LDS in group order, every thread forms its
+// channel's scale / shift, and group g then pools window 4 wg + g.  Workgroup 0 of a slot writes the BatchNorm arrays.
+__global__ __launch_bounds__(1024) void pool_finalize_bn_kernel(PoolFinalize a)
+{
+    __shared__ double rs[4][256][2];
+    __shared__ double rn[4];
+    const int slot = blockIdx.x % a.n_slots, wg = blockIdx.x / a.n_slots;
+    const int c = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int per_slot_parts = a.pfin_parts / a.n_slots;
+    double sn = 0.0, sm = 0.0, sq = 0.0;
+    for (int k0 = g; k0 < per_slot_parts; k0 += 4 * 16) {
+        float v[16], w[16];
+        int rw[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int kk = k0 + 4 * u;
+            const int idx = slot + (kk < per_slot_parts ? kk : 0) * a.n_slots;
+            rw[u] = kk < per_slot_parts ? a.pfin_rows[idx] : 0;
+            v[u] = a.pfin_sum[(size_t)idx * 256 + c];
+            w[u] = a.pfin_sq[(size_t)idx * 256 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (rw[u] > 0) {
+                const double nn = (double)rw[u], m = (double)v[u];
+                sn += nn;
+                sm += nn * m;
+                sq += (double)w[u] + nn * m * m;
+            }
+        }
+    }
+    rs[g][c][0] = sm;
+    rs[g][c][1] = sq;
+    if (c == 0) rn[g] = sn;
+    __syncthreads();
+    const double N = (rn[0] + rn[1]) + (rn[2] + rn[3]);
+    const double S = (rs[0][c][0] + rs[1][c][0]) + (rs[2][c][0] + rs[3][c][0]);
+    const double Q2 = (rs[0][c][1] + rs[1][c][1]) + (rs[2][c][1] + rs[3][c][1]);
+    const double mean = N > 0.0 ? S / N : 0.0;
+    double m2 = Q2 - N * mean * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const double var = N > 0.0 ? m2 / N : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.pfin_eps));
+    const float sc = a.pfin_gamma[c] * invstd;
+    const float sh = a.pfin_beta[c] - (float)mean * sc;
+    if (wg == 0 && g == 0) {
+        const size_t o = (size_t)slot * 256 + c;
+        a.pfin_scale[o] = sc;
+        a.pfin_shift[o] = sh;
+        a.pfin_mean[o] = (float)mean;
+        a.pfin_invstd[o] = invstd;
+        a.pfin_smean[o] = (float)mean;
+        a.pfin_suvar[o] = (float)(N > 1.0 ? m2 / (N - 1.0) : m2);
+    }
+    const int q = slot + (wg * 4 + g) * a.n_slots;
+    if (q >= a.Q) return;
+    const int orow = a.out_slot_major ? (q % a.n_slots) * (a.Q / a.n_slots) + q / a.n_slots : q;
+    float best = 0.f;
+    int arg = -1;
+    const bool use_max = sc >= 0.f;
+    for (int ch = 0; ch < a.chunks; ++ch) {
+        const size_t o = (size_t)(q * a.chunks + ch) * 256 + c;
+        const float v = a.part_max[o];
+        const int i = a.part_amax[o];
+        if (i < 0) continue;
+        if (arg < 0 || (use_max ? v > best : v < best)) {     // chunks ascend in row order: first extreme wins
+            best = v;
+            arg = i;
+        }
+    }
+    a.pooled[(size_t)orow * 256 + c] = fmaxf(fmaf(best, sc, sh), 0.f);
+    if (a.arg) a.arg[(size_t)q * 256 + c] = arg;
+    if (a.zext) a.zext[(size_t)q * 256 + c] = best;
+}
+
 int pool_finalize(const PoolFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_max && a.part_amax && a.scale && a.shift && a.pooled, "pool_finalize: null pointer");
+    AMPNET_REQUIRE(a.part_max && a.part_amax && a.pooled && (a.pfin_sum || (a.scale && a.shift)), "pool_finalize: null pointer");
     AMPNET_REQUIRE(!a.out_slot_major || a.Q % a.n_slots == 0, "pool_finalize: Q %% n_slots != 0");
+    if (a.pfin_sum) {
+        AMPNET_REQUIRE(a.C == 256 && a.pfin_sq && a.pfin_rows && a.pfin_parts >= a.n_slots && a.pfin_parts % a.n_slots == 0 && a.pfin_gamma && a.pfin_beta && a.pfin_scale &&
+                           a.pfin_shift && a.pfin_mean && a.pfin_invstd && a.pfin_smean && a.pfin_suvar,
+                       "pool_finalize: in-kernel BatchNorm finalize needs 256 channels, the producer's partials and every output array");
+        const int per_slot = cdiv(a.Q, a.n_slots);
+        hipLaunchKernelGGL(pool_finalize_bn_kernel, dim3(a.n_slots * cdiv(per_slot, 4)), dim3(1024), 0, st, a);
+        return check_launch("pool_finalize_bn_kernel");
+    }
     hipLaunchKernelGGL(pool_finalize_kernel, dim3(a.Q), dim3(256), 0, st, a);
     return check_launch("pool_finalize_kernel");
 }

@@ -372,6 +372,21 @@ def ce_backward(logits, targets, class_w, loss2, grad_scale=1.0):
     return d
 
 
+def reg_loss_backward_stack(feat_T, G, reg, coef, n_total):
+    """-> d_stack [n_total, 64, 64]: zeros in the first n_total - n matrices, coef * d(reg)/d(feat_T) in the last n (feat_T, G [n, 64, 64]): the
+    gradient of the whole stack of feature transforms in one launch (include/ampnet_hip.h: ampnet_reg_loss_bwd_stack_f32)."""
+    n = feat_T.shape[0]
+    dev = feat_T.device
+    if not (feat_T.is_contiguous() and G.is_contiguous()) or n_total < n:
+        raise _lib.AmpnetError("reg_loss_backward_stack: contiguous [n, 64, 64] tensors and n_total >= n")
+    out = torch.empty((n_total, 64, 64), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_reg_loss_bwd_stack_f32(_lib.ptr(feat_T), _lib.ptr(G), _lib.ptr(reg), ctypes.c_float(coef), n, n_total, _lib.ptr(out),
+                                                      _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_reg_loss_bwd_stack_f32")
+    return out
+
+
 def reg_loss_backward(feat_T, G, reg, coef, d_feat_T):
     """d_feat_T += coef * d(reg)/d(feat_T); feat_T, G, d_feat_T [n, 64, 64] contiguous, reg [1]."""
     n = feat_T.shape[0]

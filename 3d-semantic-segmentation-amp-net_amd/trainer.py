@@ -266,8 +266,7 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
         dist, world, on = _collectives_on()
         if on:
             pending[hg.flat.data_ptr()] = dist.all_reduce(hg.flat, op=dist.ReduceOp.SUM, async_op=True)
-    d_ft = torch.zeros_like(feat_T)
-    ops.reg_loss_backward(feat_last, G, reg, reg_weight, d_ft[-B:])
+    d_ft = ops.reg_loss_backward_stack(feat_last, G, reg, reg_weight, feat_T.shape[0])      # zeros + the regulariser's gradient, one launch
     ops.encoder_backward(ept, eg.table, xr, off, Q, total, mx, W, local, feat_T, d_lo, d_gl, d_ft, pointnet._ws, pointnet._bws)
     eg.attach()
     hg.attach()

@@ -230,6 +230,11 @@ int ampnet_cls_head_bwd_f32(const float *const *params_host, float *const *grads
 int ampnet_reg_loss_fwd_f32(const float *feat_T, int n, float *reg_out, float *G, float *part, void *stream);
 int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, const float *reg, float coef, int n, float *d_feat_T,
                             void *stream);
+/* the same gradient WRITTEN into a stack d_feat_T_stack [n_total, 64, 64] whose last n matrices are the regularised ones (the reference
+ * regularises the feature transform of the last cluster only, train_pointnet-attention.py:445): zeros in the first n_total - n, the
+ * gradient (no accumulate) in the rest -- the gradient tensor of all feature transforms without a separate zero fill.                */
+int ampnet_reg_loss_bwd_stack_f32(const float *feat_T, const float *G, const float *reg, float coef, int n, int n_total,
+                                  float *d_feat_T_stack, void *stream);
 int ampnet_ce_bwd_f32(const float *logits, const long long *targets, const float *class_w, const float *loss2,
                       float grad_scale, int B, int C, int P, float *dlogits, void *stream);
 

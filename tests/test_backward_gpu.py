@@ -142,3 +142,24 @@ def test_head_backward_matches_oracle_autograd(synth, params, drop_p, npc):
     got["__d_lo"], got["__d_gl"] = d_lo, d_gl
     assert all(torch.isfinite(g).all() for g in got.values()), "a gradient was not written"
     _check_grads(got, want[torch.float64], want[torch.float32], "head")
+
+
+@pytest.mark.gpu
+def test_reg_loss_backward_stack_matches_autograd(synth):
+    """ampnet_reg_loss_bwd_stack_f32: zeros for the windows the regulariser does not see, coef * d||I - F F^T||_F / dF (float64 autograd) for
+    the last n -- and the same numbers as the accumulate form on a zeroed tensor."""
+    ops = sub("ops")
+    n, n_total, coef = 5, 12, 0.001
+    F = torch.from_numpy(synth.uniform(7101, (n, 64, 64), -0.3, 0.3)).cuda()
+    reg, G = ops.reg_loss(F, keep_G=True)
+    stack = ops.reg_loss_backward_stack(F, G, reg, coef, n_total)
+    assert stack.shape == (n_total, 64, 64) and torch.all(stack[:n_total - n] == 0)
+    F64 = F.double().cpu().requires_grad_(True)
+    r64 = torch.norm(torch.eye(64, dtype=torch.float64) - torch.bmm(F64, F64.transpose(2, 1)))
+    r64.backward()
+    assert abs(reg.item() - r64.item()) <= 1e-5 * r64.item()
+    want = coef * F64.grad
+    assert (stack[n_total - n:].double().cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    acc = torch.zeros_like(F)
+    ops.reg_loss_backward(F, G, reg, coef, acc)
+    assert torch.equal(acc, stack[n_total - n:])
