@@ -54,6 +54,9 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None, fps_cases=None):
         m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
         if m:
             name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "")
+        m = re.match(r"ampnet::pw_bwd_bf16_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
+        if m:
+            name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "") + " bf16"
         if name and (name not in events or int(grid) > events[name]["grid"]):
             events[name] = dict(v, grid=int(grid), symbol=sym)
     # configs[4] kernels (tools/prof_fps.py: 16 clouds x 8192 points -> 4096 samples, k = 32): their own passes, their own workload size.
