@@ -219,6 +219,7 @@ struct SgProblem {
     const float *A, *B;
     float *C;
     const float *mul = nullptr;        // [M, N] with leading dimension ldc: C = (product) * mul elementwise (sgemm_mfma only)
+    const float *kscale = nullptr;     // [K]: op(A)[m][k] is multiplied by kscale[k] as it is loaded (sgemm_mfma only): A^T diag(kscale) B in one product
     float *db = nullptr;               // [M]: row sums of op(A) over K (the bias gradient G^T 1 of a weight-gradient problem), taken by the
                                        // workgroups of the first column of tiles from the A tile they stage anyway: no extra problem, no extra launch
 };
@@ -394,6 +395,10 @@ __global__ __launch_bounds__(64 * SGM_WAVES) void sgemm_mfma_kernel(SgArgs args)
                 const int k = 8 * (c0 + u) + 4 * h;
                 av[u] = sgm_fetch(g.A, g.lda, akm, avec, m0 + r, M, k, K);
                 bv[u] = sgm_fetch(g.B, g.ldb, bkm, bvec, n0 + r, N, k, K);
+                if (g.kscale) {                                  // uniform per problem
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[u][i] *= (k + i < K) ? g.kscale[k + i] : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -456,7 +461,7 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
     // AMPNET_SGEMM_VALU=1: the VALU kernel (A/B timing, tests/test_small_gemm_gpu.py compares the two)
     static const bool valu_env = [] { const char *e = getenv("AMPNET_SGEMM_VALU"); return e && e[0] == '1'; }();
     bool valu = valu_env || tl_sgemm_valu > 0;
-    for (int i = 0; i < n; ++i) valu = valu && !probs[i].mul;          // the multiply epilogue lives in the matrix-core kernel only
+    for (int i = 0; i < n; ++i) valu = valu && !probs[i].mul && !probs[i].kscale;      // the multiply epilogue / k scaling live in the matrix-core kernel only
     if (valu) {
         ProfScope prof("sgemm_small", flops, bytes, st);
         hipLaunchKernelGGL(sgemm_small_kernel, dim3(gx, gy, n), dim3(256 * SG_SK), 0, st, a);
@@ -681,7 +686,7 @@ int colsum(const float *x, int rows, int C, float *out, hipStream_t st)
 constexpr int IW_WAVES = 8, IW_U = 16;     // waves per window, rows in flight per wave: the kernel is one pass over dy (HBM)
 __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWgrad a)
 {
-    __shared__ float sx[256 * 9];
+    __shared__ __attribute__((aligned(16))) float sx[256 * 12];          // 12-float row pitch: three 16-byte reads per row
     __shared__ __attribute__((aligned(16))) float red[IW_WAVES][64][9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWg
     for (int base = row_begin; base < row_end; base += 256) {
         const int n = min(256, row_end - base);
         __syncthreads();
-        for (int e = tid; e < n * 9; e += 64 * IW_WAVES) sx[e] = a.x[(size_t)base * 9 + e];
+        for (int e = tid; e < n * 9; e += 64 * IW_WAVES) sx[(e / 9) * 12 + e % 9] = a.x[(size_t)base * 9 + e];
         __syncthreads();
         for (int i0 = wave; i0 < n; i0 += IW_WAVES * IW_U) {        // IW_U rows per trip: all loads first, then the FMAs
             float dyv[IW_U];
@@ -774,16 +779,18 @@ __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWg
             for (int u = 0; u < IW_U; ++u) {
                 const int i = i0 + IW_WAVES * u;
                 if (i < n) {
+                    const sg_f32x4 x0 = *reinterpret_cast<const sg_f32x4 *>(sx + i * 12), x1 = *reinterpret_cast<const sg_f32x4 *>(sx + i * 12 + 4);
+                    const float xr[9] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], sx[i * 12 + 8]};
                     float z = 0.f;
                     if (three) {
-                        z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
+                        z = xr[0] * w[0] + xr[1] * w[1] + xr[2] * w[2];
                     } else {
 #pragma unroll
-                        for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+                        for (int f = 0; f < 9; ++f) z = fmaf(xr[f], w[f], z);
                     }
                     const float g = fmaf(dyv[u], p1, fmaf(z, p2, p3));
 #pragma unroll
-                    for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, sx[i * 9 + f], acc[f]);
+                    for (int f = 0; f < 9; ++f) acc[f] = fmaf(g, xr[f], acc[f]);
                 }
             }
         }
@@ -1263,6 +1270,18 @@ __global__ __launch_bounds__(256) void slot_mats_kernel(const float *__restrict_
 int slot_mats(const float *W, const float *P2, const float *P3, int n_slots, int C, int cp, float *G, float *c0, hipStream_t st)
 {
     AMPNET_REQUIRE(W && P2 && P3 && G && c0 && cp >= 1 && cp <= 128 && C >= 1, "slot_mats: bad arguments (cp=%d)", cp);
+    if (n_slots + 1 <= SG_MAX_PROBLEMS) {
+        // G[s] = W^T diag(P2[s]) W and c0 = P3 W as ONE launch of the matrix-core small GEMM: n_slots problems [cp, cp, K = C] whose A operand is
+        // scaled along k as it is loaded, + one [n_slots, cp, K = C] problem (the VALU kernel below made eight load -> barrier -> multiply trips
+        // on 81 workgroups: 24.6 us per pooled layer)
+        SgProblem p[SG_MAX_PROBLEMS];
+        for (int s2 = 0; s2 < n_slots; ++s2) {
+            p[s2] = {cp, cp, C, 1, 0, cp, cp, cp, 0, W, W, G + (size_t)s2 * cp * cp};
+            p[s2].kscale = P2 + (size_t)s2 * C;
+        }
+        p[n_slots] = {n_slots, cp, C, 0, 0, C, cp, cp, 0, P3, W, c0};
+        return sgemm_launch(p, n_slots + 1, st);
+    }
     hipLaunchKernelGGL(slot_mats_kernel, dim3(cdiv(cp, SM_J) + 1, n_slots), dim3(256), 0, st, W, P2, P3, C, cp, G, c0);
     return check_launch("slot_mats_kernel");
 }
@@ -1300,7 +1319,7 @@ int reduce_slots2(const float *part0, int n_el0, float *out0, const float *part1
 }
 
 // block = output channel c, thread = input channel k
-constexpr int PWG_G = 4;       // thread groups per output channel: 4 x more gathers in flight than one group
+constexpr int PWG_G = 8;       // thread groups per output channel: with sixteen gathers in flight per thread a channel's 576 rows are five trips
 
 template <bool ZB> __global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_kernel(PooledWgrad a)
 {
@@ -1326,27 +1345,51 @@ template <bool ZB> __global__ __launch_bounds__(128 * PWG_G) void pooled_wgrad_k
     __syncthreads();
     float acc = 0.f;
     if (k < a.cp) {
-        // dense part: slots s = grp, grp + 4, ...
-        for (int s = grp; s < a.n_slots; s += PWG_G) {
-            float m = 0.f;
-            const float *g = a.gram + (size_t)s * a.cp * a.cp;
+        if (a.wgram) {
+            // dense part from W Gram[s] (a.wgram [S, C, cp], one launch of the matrix-core small GEMM before this kernel): two loads per slot,
+            // all independent -- the walk over Gram rows below is sixteen dependent trips of eight L2 loads per slot (33 of this kernel's 46 us)
+            for (int s = grp; s < a.n_slots; s += PWG_G) {
+                acc = fmaf(a.P2[(size_t)s * a.C + c], a.wgram[((size_t)s * a.C + c) * a.cp + k], acc);
+                acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
+            }
+        } else {
+            // dense part: slots s = grp, grp + 4, ...
+            for (int s = grp; s < a.n_slots; s += PWG_G) {
+                float m = 0.f;
+                const float *g = a.gram + (size_t)s * a.cp * a.cp;
 #pragma unroll 8
-            for (int j = 0; j < a.cp; ++j) m = fmaf(sW[j], g[(size_t)j * a.cp + k], m);
-            acc = fmaf(a.P2[(size_t)s * a.C + c], m, acc);
-            acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
+                for (int j = 0; j < a.cp; ++j) m = fmaf(sW[j], g[(size_t)j * a.cp + k], m);
+                acc = fmaf(a.P2[(size_t)s * a.C + c], m, acc);
+                acc = fmaf(a.P3[(size_t)s * a.C + c], a.asum[(size_t)s * a.cp + k], acc);
+            }
         }
         // sparse part: gathers of the argmax rows, windows q = grp, grp + 4, ...; independent loads so that they pipeline
         const float *__restrict__ zp = a.z_prev;
-#pragma unroll 8
-        for (int q = grp; q < a.Q; q += PWG_G) {
-            const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
-            const float av = fmaxf(fmaf(ld_act_t<ZB>(zp, (size_t)sRow[q] * a.cp + k), sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f);
-            acc = fmaf(sCoef[q], av, acc);
+        for (int q0 = grp; q0 < a.Q; q0 += PWG_G * 16) {
+            float zv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int q = q0 + PWG_G * u;
+                zv[u] = ld_act_t<ZB>(zp, (size_t)sRow[q < a.Q ? q : q0] * a.cp + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int q = q0 + PWG_G * u;
+                if (q < a.Q) {
+                    const int slot = a.n_slots > 1 ? q % a.n_slots : 0;
+                    acc = fmaf(sCoef[q], fmaxf(fmaf(zv[u], sS[slot * a.cp + k], sT[slot * a.cp + k]), 0.f), acc);
+                }
+            }
         }
     }
     sRed[grp][k] = acc;
     __syncthreads();
-    if (grp == 0 && k < a.cp) a.dW[(size_t)c * a.cp + k] = (sRed[0][k] + sRed[1][k]) + (sRed[2][k] + sRed[3][k]);
+    if (grp == 0 && k < a.cp) {
+        float v = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < PWG_G; ++g2) v += sRed[g2][k];
+        a.dW[(size_t)c * a.cp + k] = v;
+    }
 }
 
 int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
@@ -1354,6 +1397,14 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
     AMPNET_REQUIRE(a.W && a.P1 && a.P2 && a.P3 && a.gram && a.asum && a.arg && a.dpm && a.z_prev && a.s_prev && a.t_prev && a.dW, "pooled_wgrad: null pointer");
     const size_t lds = ((size_t)a.Q * 2 + (size_t)a.n_slots * a.cp * 2) * sizeof(int);
     AMPNET_REQUIRE(a.cp <= 128 && lds <= 60 * 1024, "pooled_wgrad: cp=%d Q=%d n_slots=%d", a.cp, a.Q, a.n_slots);
+    if (a.wgram) {
+        AMPNET_REQUIRE(a.n_slots <= SG_MAX_PROBLEMS, "pooled_wgrad: %d slots in one GEMM launch", a.n_slots);
+        SgProblem p[SG_MAX_PROBLEMS];
+        for (int s2 = 0; s2 < a.n_slots; ++s2)
+            p[s2] = {a.C, a.cp, a.cp, 0, 0, a.cp, a.cp, a.cp, 0, a.W, a.gram + (size_t)s2 * a.cp * a.cp, a.wgram + (size_t)s2 * a.C * a.cp};
+        int rc = sgemm_launch(p, a.n_slots, st);
+        if (rc != AMPNET_OK) return rc;
+    }
     if (a.z_bf16) hipLaunchKernelGGL(pooled_wgrad_kernel<true>, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
     else hipLaunchKernelGGL(pooled_wgrad_kernel<false>, dim3(a.C), dim3(128 * PWG_G), lds, st, a);
     return check_launch("pooled_wgrad_kernel");
@@ -1363,12 +1414,13 @@ int pooled_wgrad(const PooledWgrad &a, hipStream_t st)
 
 // ---- the token-level products of the backward behind the C ABI (tests/test_small_gemm_gpu.py) ----------------------------------------
 extern "C" int ampnet_small_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
-                                     int accumulate, float *row_sums, void *stream)
+                                     int accumulate, float *row_sums, const float *k_scale, void *stream)
 {
     AMPNET_REQUIRE(A && B && C, "ampnet_small_gemm_f32: null pointer");
     AMPNET_REQUIRE(M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N, "ampnet_small_gemm_f32: M=%d N=%d K=%d lda=%d ldb=%d ldc=%d", M, N, K, lda, ldb, ldc);
     ampnet::SgProblem p = {M, N, K, trans_a, trans_b, lda, ldb, ldc, accumulate, A, B, C};
     p.db = row_sums;
+    p.kscale = k_scale;
     return ampnet::sgemm_launch(&p, 1, (hipStream_t)stream);
 }
 

@@ -50,9 +50,8 @@ struct EncBwdWs {
     float *fc_split;                                 // [8, Q, 128] K-split partials of the 4096-output fc_3 data gradient
     float *dT64, *dT64t;       // [Q, 4096]
     float *dWeff, *dT3;        // [Q, 576], [Q, 12]
-    float *srows, *Gm, *c0, *gram, *asum;   // [Q*256,128] [S,128,128] [S,128] [S,128,128] [S,128]: pooled-layer algebra
+    float *srows, *Gm, *c0, *gram, *asum, *wgram;   // [Q*256,128] [S,128,128] [S,128] [S,128,128] [S,128] [S,256,128]: pooled-layer algebra
     int *srow_row, *srow_cnt;  // [Q*256], [Q]
-    float *ones64, *zeros64;   // [n_slots, 64] identity BatchNorm-backward constants (g = dy) for the fused bmm backward
     BnBwdSlot bn[BN_ENC_COUNT];
     size_t bytes;
 };
@@ -103,11 +102,10 @@ void enc_bwd_carve(const EncShape &s, void *base, EncBwdWs &w)
     w.Gm = c.take<float>((size_t)s.n_slots * 128 * 128);
     w.c0 = c.take<float>((size_t)s.n_slots * 128);
     w.gram = c.take<float>((size_t)s.n_slots * 128 * 128);
+    w.wgram = c.take<float>((size_t)s.n_slots * 256 * 128);
     w.asum = c.take<float>((size_t)s.n_slots * 128);
     w.srow_row = c.take<int>(Q * 256);
     w.srow_cnt = c.take<int>(Q);
-    w.ones64 = c.take<float>((size_t)s.n_slots * 64);
-    w.zeros64 = c.take<float>((size_t)s.n_slots * 64);
     for (int i = 0; i < BN_ENC_COUNT; ++i) {
         const size_t n = (size_t)s.n_slots * kBnC2[i];
         w.bn[i].P1 = c.take<float>(n);
@@ -332,6 +330,7 @@ struct EncBwd {
         pw.arg = arg; pw.dpm = b.dpm; pw.slot_major = slot_major;
         pw.z_prev = z_prev; pw.s_prev = f.bn[prev_bn].scale; pw.t_prev = f.bn[prev_bn].shift; pw.z_bf16 = zb ? 1 : 0;
         pw.Q = s.Q; pw.n_slots = s.n_slots; pw.dW = dW;
+        if (s.n_slots <= 10) pw.wgram = b.wgram;
         SparseFix sf;
         sf.srows = b.srows; sf.srow_row = b.srow_row; sf.srow_cnt = b.srow_cnt; sf.z_prev = z_prev;
         sf.s_prev = f.bn[prev_bn].scale; sf.t_prev = f.bn[prev_bn].shift; sf.mean_prev = f.bn[prev_bn].mean; sf.invstd_prev = f.bn[prev_bn].invstd;

@@ -451,6 +451,7 @@ struct PooledWgrad {
     const float *z_prev = nullptr, *s_prev = nullptr, *t_prev = nullptr;   // [rows, cp], [S, cp]
     int Q = 0, n_slots = 1, C = 256, cp = 128;
     float *dW = nullptr;                // [C, cp]
+    float *wgram = nullptr;             // optional scratch [S, C, cp]: W Gram[s] by one small-GEMM launch instead of a walk over Gram rows per thread
 };
 int pooled_wgrad(const PooledWgrad &a, hipStream_t st);
 

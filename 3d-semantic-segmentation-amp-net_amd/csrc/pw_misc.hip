@@ -8,6 +8,8 @@
 
 namespace ampnet {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ----------------------------------------------------------------------------------------------------
 // pw_input: 64 output channels, lane = channel, a wave walks rows.  HBM-bound (36 B in, 256 B out per
 // point), so the layout that matters is the coalesced 256-byte row store; x rows are staged through LDS.
@@ -16,7 +18,7 @@ constexpr int IN_ROWS = 256;   // rows staged per pass
 
 __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
 {
-    __shared__ float sx[IN_ROWS * 9];
+    __shared__ __attribute__((aligned(16))) float sx[IN_ROWS * 12];
     __shared__ float red[4][64][3];
     __shared__ int red_n[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,21 +59,30 @@ __global__ __launch_bounds__(256) void pw_input_kernel(PwInput a)
             const int n = min(IN_ROWS, row_end - base);
             __syncthreads();
             {
+                // rows on a 12-float pitch: a row's nine features are three 16-byte LDS reads below instead of nine 4-byte ones
                 float tmp[9];
 #pragma unroll
                 for (int u = 0; u < 9; ++u) tmp[u] = (tid + 256 * u) < n * 9 ? a.x[(size_t)base * 9 + tid + 256 * u] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 9; ++u)
-                    if ((tid + 256 * u) < n * 9) sx[tid + 256 * u] = tmp[u];
+                for (int u = 0; u < 9; ++u) {
+                    const int e = tid + 256 * u;
+                    if (e < n * 9) sx[(e / 9) * 12 + e % 9] = tmp[u];
+                }
             }
             __syncthreads();
             for (int i = wave; i < n; i += 4) {
                 float z = 0.f;
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(sx + i * 12);
                 if (nf == 3) {
-                    z = sx[i * 9 + 0] * w[0] + sx[i * 9 + 1] * w[1] + sx[i * 9 + 2] * w[2];
+                    z = x0[0] * w[0] + x0[1] * w[1] + x0[2] * w[2];
                 } else {
+                    const f32x4 x1 = *reinterpret_cast<const f32x4 *>(sx + i * 12 + 4);
+                    const float x8 = sx[i * 12 + 8];
 #pragma unroll
-                    for (int f = 0; f < 9; ++f) z = fmaf(sx[i * 9 + f], w[f], z);
+                    for (int f = 0; f < 4; ++f) z = fmaf(x0[f], w[f], z);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) z = fmaf(x1[f], w[4 + f], z);
+                    z = fmaf(x8, w[8], z);
                 }
                 if (a.z_bf16) reinterpret_cast<__bf16 *>(a.Z)[(size_t)(base + i) * 64 + lane] = (__bf16)z;
                 else a.Z[(size_t)(base + i) * 64 + lane] = z;

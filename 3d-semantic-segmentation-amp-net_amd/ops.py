@@ -276,7 +276,7 @@ def pad_mask(targets, W):
     return mask
 
 
-def small_gemm(A, B, trans_a=False, trans_b=False, out=None, accumulate=False, want_row_sums=False):
+def small_gemm(A, B, trans_a=False, trans_b=False, out=None, accumulate=False, want_row_sums=False, k_scale=None):
     """C (+)= op(A) op(B) on the kernel the backward uses for its token-level products (include/ampnet_hip.h: ampnet_small_gemm_f32).
     A, B: 2-D float32 GPU tensors whose rows are contiguous (a column slice of a wider matrix is fine: the leading dimension is its stride)."""
     _lib.require_gpu(A, "A")
@@ -294,7 +294,8 @@ def small_gemm(A, B, trans_a=False, trans_b=False, out=None, accumulate=False, w
     with torch.cuda.device(A.device):
         vp = ctypes.c_void_p
         rc = _lib.lib().ampnet_small_gemm_f32(int(trans_a), int(trans_b), M, N, K, vp(A.data_ptr()), A.stride(0), vp(B.data_ptr()), B.stride(0),
-                                              vp(out.data_ptr()), out.stride(0), int(accumulate), _lib.ptr(rs), _lib.stream_ptr(A.device))
+                                              vp(out.data_ptr()), out.stride(0), int(accumulate), _lib.ptr(rs),
+                                              _lib.ptr(k_scale.contiguous().float()) if k_scale is not None else None, _lib.stream_ptr(A.device))
     _lib.check(rc, "ampnet_small_gemm_f32")
     return (out, rs) if want_row_sums else out
 

@@ -251,13 +251,15 @@ int ampnet_confusion_i64(const long long *preds, const long long *targets, long 
 
 /* ---- the token-level products of the backward (one row per window: the attention projections, the T-Net FC layers) ---------------------
  * C [M, N] (+)= op(A) op(B), op(A) = A [M, K] (trans_a = 0) or A^T with A [K, M]; op(B) = B [K, N] (trans_b = 0) or B^T with B [N, K];
- * row-major with leading dimensions lda / ldb / ldc; accumulate != 0 adds to C.  row_sums (optional, [M]) receives sum_k op(A)[m][k]:
+ * row-major with leading dimensions lda / ldb / ldc; accumulate != 0 adds to C.  k_scale (optional, [K]): op(A)[m][k] is multiplied by k_scale[k]
+ * as it is loaded, i.e. C = op(A) diag(k_scale) op(B) (the per-slot matrices W^T diag(P2) W of the pooled layers' backward); it also scales the
+ * row sums.  row_sums (optional, [M]) receives sum_k op(A)[m][k]:
  * the bias gradient G^T 1 that rides in a weight-gradient product dW = G^T X (reference: autograd of nn.Linear / nn.MultiheadAttention
  * as train_pointnet-attention.py:463-467 calls it; this is not a reference interface, it is exported so that the kernel the backward
  * calls ~11 times per step can be tested on its own).  fp32 matrix cores, K split over the 16 waves of a workgroup in a fixed order:
  * bitwise reproducible.                                                                                                             */
 int ampnet_small_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C,
-                          int ldc, int accumulate, float *row_sums, void *stream);
+                          int ldc, int accumulate, float *row_sums, const float *k_scale, void *stream);
 
 /* ---- a8 on the device: the input pipeline of train_loop in one kernel --------------------------------------------
  * replaces the host augmentation of train_pointnet-attention.py:390-405 (shuffle_clusters utils/utils.py:620-632,

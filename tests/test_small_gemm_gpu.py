@@ -63,6 +63,21 @@ def test_small_gemm_matches_float64(synth, ta, tb, M, N, K, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ta,tb,M,N,K", [(True, False, 128, 128, 256), (False, False, 9, 128, 256), (True, True, 33, 31, 70)])
+def test_small_gemm_k_scale(synth, ta, tb, M, N, K):
+    """C = op(A) diag(k_scale) op(B): the form the pooled layers' per-slot matrices W^T diag(P2) W use."""
+    ops = sub("ops")
+    A, Bm = _operands(synth, 5200 + M + N + K, ta, tb, M, N, K, 0, 0, 0)
+    ks = torch.from_numpy(synth.uniform(5300 + K, (K,), -2.0, 2.0)).cuda()
+    opA = (A.t() if ta else A).double().cpu()
+    opB = (Bm.t() if tb else Bm).double().cpu()
+    want = (opA * ks.double().cpu()[None, :]) @ opB
+    out, rs = ops.small_gemm(A, Bm, ta, tb, want_row_sums=True, k_scale=ks)
+    assert (out.double().cpu() - want).abs().max().item() <= 2e-5 * np.sqrt(K) * float(opA.abs().max() * opB.abs().max())
+    assert (rs.double().cpu() - (opA * ks.double().cpu()[None, :]).sum(1)).abs().max().item() <= 4e-6 * K
+
+
+@pytest.mark.gpu
 def test_small_gemm_rejects_bad_operands(synth):
     ops, L = sub("ops"), sub("_lib")
     A = torch.zeros((8, 4), device="cuda")
