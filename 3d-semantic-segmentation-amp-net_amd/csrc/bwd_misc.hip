@@ -824,23 +824,25 @@ int pw_input_wgrad(const PwInputWgrad &a, hipStream_t st)
 // mode 0 (T-Net conv_1 on xyz): dW[c][f] = sum_q dWeff[q][c][f], f < 3
 // mode 1 (encoder conv_1):      dW[c][3+f] = sum_q dWeff[q][c][f];  dW[c][d] = sum_q sum_i T[p(q)][i][d] * dWeff[q][c][i];
 //                               dT[p(q)][i][d] = sum_c dWeff[q][c][i] * W[c][d]
+constexpr int IPG_WB = 16;     // weight-gradient blocks of input_param_grads (4 channels each)
 __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__restrict__ dWeff, const float *__restrict__ W,
                                                                const float *__restrict__ T, int Q, int n_slots, int slot_major, int mode,
                                                                float *__restrict__ dW, float *__restrict__ dT)
 {
-    if (blockIdx.x < 4) {
-        // blocks 0..3: the weight gradient of 16 channels each, thread = (channel c, window group g of 16); groups summed in fixed order
-        __shared__ float red[16][16][12];
-        const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
+    if (blockIdx.x < IPG_WB) {
+        // blocks 0..15: the weight gradient of 4 channels each, thread = (channel c, window group g of 64); groups summed in fixed order.
+        // 64 groups: a thread walks Q / 64 windows, four per trip with their loads (9 gradient values, 9 transform entries each) issued before
+        // the first use -- three dependent trips at Q = 576 (nine with the 4 x 16-group blocks before: 21.6 us)
+        __shared__ float red[64][4][12];
+        const int cl = threadIdx.x & 3, c = blockIdx.x * 4 + cl, g = threadIdx.x >> 2;
         float s[12];
 #pragma unroll
         for (int f = 0; f < 12; ++f) s[f] = 0.f;
-        // four windows per trip: their loads (9 gradient values, 9 transform entries each) are issued before the first use
-        for (int q0 = g; q0 < Q; q0 += 64) {
+        for (int q0 = g; q0 < Q; q0 += 64 * 4) {
             float ev[4][9], tv[4][9];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int q = q0 + 16 * u;
+                const int q = q0 + 64 * u;
                 const bool live = q < Q;
                 const float *e = dWeff + ((size_t)(live ? q : 0) * 64 + c) * 9;
                 const int p = slot_major ? ((live ? q : 0) % n_slots) * (Q / n_slots) + (live ? q : 0) / n_slots : (live ? q : 0);
@@ -870,14 +872,14 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
             const int nf = mode == 0 ? 3 : 12;
             for (int f = 0; f < nf; ++f) {
                 float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v += red[k][cl][f];
+#pragma unroll 16
+                for (int k = 0; k < 64; ++k) v += red[k][cl][f];
                 dW[c * nf + f] = v;
             }
         }
     } else if (mode == 1) {
-        // blocks 4..: dT for windows, one (q, i, d) per thread
-        const int idx = (blockIdx.x - 4) * 256 + threadIdx.x;
+        // blocks IPG_WB..: dT for windows, one (q, i, d) per thread
+        const int idx = (blockIdx.x - IPG_WB) * 256 + threadIdx.x;
         if (idx >= Q * 9) return;
         const int q = idx / 9, i = (idx % 9) / 3, d = idx % 3;
         const int p = slot_major ? (q % n_slots) * (Q / n_slots) + q / n_slots : q;
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(256) void input_param_grads_kernel(const float *__r
 int input_param_grads(const float *dWeff, const float *W, const float *T, int Q, int n_slots, int slot_major, int mode, float *dW,
                       float *dT, hipStream_t st)
 {
-    const int blocks = 4 + (mode == 1 ? cdiv(Q * 9, 256) : 0);
+    const int blocks = IPG_WB + (mode == 1 ? cdiv(Q * 9, 256) : 0);
     hipLaunchKernelGGL(input_param_grads_kernel, dim3(blocks), dim3(256), 0, st, dWeff, W, T, Q, n_slots, slot_major, mode, dW, dT);
     return check_launch("input_param_grads_kernel");
 }
@@ -948,14 +950,29 @@ __global__ __launch_bounds__(256) void transpose64_kernel(const float *__restric
     __shared__ float t[64][65];
     const int q = blockIdx.x;
     const size_t p = (size_t)(q % n_slots) * (Q / n_slots) + q / n_slots;
-    for (int e = threadIdx.x; e < 4096; e += 256) {
-        float s = 0.f;
-        for (int ch = 0; ch < chunks; ++ch) {              // the window's partials, in order
-            // by_workgroup: partials indexed like pw_bwd_fused's workgroups, ((q / n_slots) * chunks + ch) * n_slots + q % n_slots
-            const size_t pi = by_workgroup ? ((size_t)(q / n_slots) * chunks + ch) * n_slots + q % n_slots : (size_t)q * chunks + ch;
-            s += src[pi * 4096 + e];
+    // the window's partials, summed in chunk order; four elements x up to eight chunks of loads in flight per thread (the plain nest waited for
+    // every load in turn: 42 us for 75 MB)
+    // by_workgroup: partials indexed like pw_bwd_fused's workgroups, ((q / n_slots) * chunks + ch) * n_slots + q % n_slots
+    for (int e0 = threadIdx.x; e0 < 4096; e0 += 256 * 4) {
+        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < chunks; c0 += 8) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = c0 + i < chunks ? c0 + i : c0;
+                    const size_t pi = by_workgroup ? ((size_t)(q / n_slots) * chunks + ch) * n_slots + q % n_slots : (size_t)q * chunks + ch;
+                    v[u][i] = src[pi * 4096 + e0 + 256 * u];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c0 + i < chunks) sacc[u] += v[u][i];
         }
-        t[e / 64][e % 64] = s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[(e0 + 256 * u) / 64][(e0 + 256 * u) % 64] = sacc[u];
     }
     __syncthreads();
     // + add (same layout as dst): the gradient that reaches the transforms from outside (the regulariser), no separate axpy launch

@@ -6,15 +6,17 @@
 namespace ampnet {
 
 // one block per matrix: G = I - F F^T held in LDS; out_part[m] = sum G^2; optionally keeps G for the backward
-__global__ __launch_bounds__(256) void reg_fwd_kernel(const float *__restrict__ F, float *__restrict__ part, float *__restrict__ G)
+// 1024 threads per matrix (four outputs each): B = 64 matrices are 64 workgroups, so the launch is as long as ONE workgroup takes
+constexpr int REG_T = 1024;
+__global__ __launch_bounds__(REG_T) void reg_fwd_kernel(const float *__restrict__ F, float *__restrict__ part, float *__restrict__ G)
 {
     __shared__ float sF[64][65];
-    __shared__ float red[4];
+    __shared__ float red[REG_T / 64];
     const int m = blockIdx.x, tid = threadIdx.x;
-    for (int e = tid; e < 4096; e += 256) sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
+    for (int e = tid; e < 4096; e += REG_T) sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
     __syncthreads();
     float acc = 0.f;
-    for (int e = tid; e < 4096; e += 256) {
+    for (int e = tid; e < 4096; e += REG_T) {
         const int i = e / 64, j = e % 64;
         float d = 0.f;
 #pragma unroll 8
@@ -27,7 +29,12 @@ __global__ __launch_bounds__(256) void reg_fwd_kernel(const float *__restrict__ 
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) part[m] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < REG_T / 64; ++w) v += red[w];
+        part[m] = v;
+    }
 }
 
 __global__ void reg_finalize_kernel(const float *__restrict__ part, int n, float *__restrict__ out)
@@ -42,26 +49,26 @@ __global__ void reg_finalize_kernel(const float *__restrict__ part, int n, float
 // dF += coef * d(reg)/dF,  d(reg)/dF = -2 G F / reg   (G symmetric)
 // lead > 0: dF is a stack of lead + n matrices that is WRITTEN: zeros in the first `lead` (the windows the regulariser does not see), the
 // gradient itself in the last n (no accumulate): the caller then needs no zero fill of the stack (9.4 MB and a launch per step)
-__global__ __launch_bounds__(256) void reg_bwd_kernel(const float *__restrict__ F, const float *__restrict__ G,
+__global__ __launch_bounds__(REG_T) void reg_bwd_kernel(const float *__restrict__ F, const float *__restrict__ G,
                                                      const float *__restrict__ reg, float coef, float *__restrict__ dF, int lead, int write)
 {
     __shared__ float sF[64][65], sG[64][65];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < lead) {
         float4 *z = reinterpret_cast<float4 *>(dF + (size_t)blockIdx.x * 4096);
-        for (int e = tid; e < 1024; e += 256) z[e] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int e = tid; e < 1024; e += REG_T) z[e] = float4{0.f, 0.f, 0.f, 0.f};
         return;
     }
     const int m = (int)blockIdx.x - lead;
     dF += (size_t)lead * 4096;
-    for (int e = tid; e < 4096; e += 256) {
+    for (int e = tid; e < 4096; e += REG_T) {
         sF[e / 64][e % 64] = F[(size_t)m * 4096 + e];
         sG[e / 64][e % 64] = G[(size_t)m * 4096 + e];
     }
     __syncthreads();
     const float r = reg[0];
     const float k = r > 0.f ? -2.0f * coef / r : 0.f;
-    for (int e = tid; e < 4096; e += 256) {
+    for (int e = tid; e < 4096; e += REG_T) {
         const int i = e / 64, j = e % 64;
         float d = 0.f;
 #pragma unroll 8
@@ -105,7 +112,7 @@ extern "C" int ampnet_reg_loss_fwd_f32(const float *feat_T, int n, float *reg_ou
 {
     AMPNET_REQUIRE(feat_T && reg_out && part && n >= 1, "ampnet_reg_loss_fwd_f32: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(reg_fwd_kernel, dim3(n), dim3(256), 0, st, feat_T, part, G);
+    hipLaunchKernelGGL(reg_fwd_kernel, dim3(n), dim3(REG_T), 0, st, feat_T, part, G);
     hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(64), 0, st, part, n, reg_out);
     return check_launch("reg_loss_fwd");
 }
@@ -114,7 +121,7 @@ extern "C" int ampnet_reg_loss_bwd_f32(const float *feat_T, const float *G, cons
                                        void *stream)
 {
     AMPNET_REQUIRE(feat_T && G && reg && d_feat_T && n >= 1, "ampnet_reg_loss_bwd_f32: bad arguments");
-    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T, 0, 0);
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n), dim3(REG_T), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T, 0, 0);
     return check_launch("reg_loss_bwd");
 }
 
@@ -122,7 +129,7 @@ extern "C" int ampnet_reg_loss_bwd_stack_f32(const float *feat_T, const float *G
                                              void *stream)
 {
     AMPNET_REQUIRE(feat_T && G && reg && d_feat_T_stack && n >= 1 && n_total >= n, "ampnet_reg_loss_bwd_stack_f32: bad arguments");
-    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n_total), dim3(256), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T_stack, n_total - n, 1);
+    hipLaunchKernelGGL(reg_bwd_kernel, dim3(n_total), dim3(REG_T), 0, (hipStream_t)stream, feat_T, G, reg, coef, d_feat_T_stack, n_total - n, 1);
     return check_launch("reg_loss_bwd_stack");
 }
 
