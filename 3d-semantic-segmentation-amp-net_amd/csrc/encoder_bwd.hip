@@ -404,7 +404,8 @@ struct EncBwd {
         LinBwdOpt o3;
         o3.db = G[pbase + TP_FC3_B];
         // fc_3: z3 = a2 W3^T + b3
-        if (kk >= 1024)
+        static const bool ksplit = [] { const char *v = getenv("AMPNET_FC3_KSPLIT"); return !(v && v[0] == '0'); }();
+        if (kk >= 1024 && ksplit)
             TRY(sgemm_linear_bwd_ksplit(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, b.fc_split, 8, st, o3));
         else
             TRY(sgemm_linear_bwd(Q, kk, 128, g3, kk, b.a2, 128, P[pbase + TP_FC3_W], 128, G[pbase + TP_FC3_W], 128, b.da2, 128, st, o3));

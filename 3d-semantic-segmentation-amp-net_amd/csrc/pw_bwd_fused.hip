@@ -38,6 +38,9 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                                                     // they never wait on a load behind their own pending stores
     constexpr int QX = CX / 4, QY = CY / 4, SX = FB_STAGE / QX, SY = FB_STAGE / QY;
     constexpr int NIX = ROWS / SX, NIY = ROWS / SY;
+    // (Round 3 tried twice the rows per block for the 64-input layers -- <64,64,128>, <64,128,64>, two data-gradient tiles per D wave, half the barriers
+    // per MFMA: 255 -> 335 us and 475 -> 495 us, the doubled staging registers spill and the roles pipeline worse.  Static wave priorities for either
+    // role: +-0.5 %.  Both A/B'd on one box, gpurun_out r3A / r3z.)
     static_assert((ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
     static_assert(NIX >= 1 && NIY >= 1, "staging shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
