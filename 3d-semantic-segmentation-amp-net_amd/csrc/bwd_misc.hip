@@ -768,6 +768,9 @@ __global__ __launch_bounds__(64 * IW_WAVES) void pw_input_wgrad_kernel(PwInputWg
         __syncthreads();
         for (int e = tid; e < n * 9; e += 64 * IW_WAVES) sx[(e / 9) * 12 + e % 9] = a.x[(size_t)base * 9 + e];
         __syncthreads();
+        // (Round 3 also tried: the dy loads of the next trip issued before the current trip's FMAs -- 90 -> 92 us, the kernel is VALU-bound
+        // (~26 instructions per row and wave) with 576 workgroups on 256 CUs, not waiting for loads; and a three-feature branch for the xyz-only
+        // T-Net layer -- 90 -> 120 us, the branch inside the unrolled trip costs more than the six FMAs it saves.)
         for (int i0 = wave; i0 < n; i0 += IW_WAVES * IW_U) {        // IW_U rows per trip: all loads first, then the FMAs
             float dyv[IW_U];
 #pragma unroll
