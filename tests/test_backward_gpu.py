@@ -47,7 +47,8 @@ def _check_grads(got, want64, want32, what):
     assert not bad, f"{what} (worst torch-fp32 relative noise {rel_floor:.2e}): " + "; ".join(f"{k}: err {e:.3e} fp32-noise {n:.3e} |g| {r:.3e}" for k, e, n, r in bad[:8])
 
 
-@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160), (64, 2, 64), (64, 2, 300), (4, 3, 700), (64, 2, 544)])
+# (8, 12, 64): more BatchNorm slots than one small-GEMM launch holds problems -- the per-slot matrices of the pooled layers take their fallback kernels
+@pytest.mark.parametrize("B,W,N", [(8, 2, 96), (16, 3, 160), (64, 2, 64), (64, 2, 300), (4, 3, 700), (64, 2, 544), (8, 12, 64)])
 def test_encoder_backward_matches_oracle_autograd(synth, params, B, W, N):
     ops = sub("ops")
     p = {k: torch.from_numpy(v).cuda() for k, v in synth.make_params(5, params.ENC_PARAMS).items()}
