@@ -308,6 +308,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     f32x4 a_cur[4], a_nxt[4], a_nx2[4];
     // bf16 kernels: the matrix work of a 32-k block is 8 MFMAs of 32 cycles, far shorter than a trip to HBM, so ONE block in flight per
     // wave caps the kernel at bytes-in-flight / latency (about 4 TB/s measured); they keep TWO blocks in flight (a_nxt, a_nx2)
+    // (fp32 kernels with NT <= 2 -- <= 1 us of matrix work per block and wave, 4.4 .. 4.8 TB/s -- were tried with two blocks in flight as well in
+    // round 3: every one of them 1 .. 13 % SLOWER on the same box (gpurun_out r3C): they do not wait for their loads either.)
     constexpr int PF = BF ? 2 : 1;
 
     auto frag_ptr = [&](int tile, int kb) -> const float * {
