@@ -181,7 +181,9 @@ struct EncRun {
         g.n_slots = s.train ? s.n_slots : 1;
         g.Z = Z; g.ldz = cout; g.cout = cout;
         if (stats) { g.part_sum = psum(region); g.part_sq = psq(region); }
-        if (pool) { g.part_max = ws.part_max; g.part_amax = ws.part_amax; g.pool_gamma = bnp[pool_bn].gamma; }
+        // eval forward in fp32: only the extremes are tracked (no argmax rows: nothing reads them without a backward)
+        const bool rows_too = s.train || matrix_precision() != AMPNET_PRECISION_F32;
+        if (pool) { g.part_max = ws.part_max; g.part_amax = rows_too ? ws.part_amax : nullptr; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
         if (stats) {                                             // one partial per workgroup: bn_finalize in one stage (kernels.h)
             g.part_rows = prows(region);
@@ -272,11 +274,12 @@ struct EncRun {
             p.pfin_scale = bs.scale; p.pfin_shift = bs.shift; p.pfin_mean = bs.mean; p.pfin_invstd = bs.invstd; p.pfin_smean = bs.smean; p.pfin_suvar = bs.suvar;
             pend.bn = -1;
         } else if (int rc = settle(); rc != AMPNET_OK) return rc;
-        p.part_max = ws.part_max; p.part_amax = ws.part_amax;
+        const bool rows_too = s.train || matrix_precision() != AMPNET_PRECISION_F32;
+        p.part_max = ws.part_max; p.part_amax = rows_too ? ws.part_amax : nullptr;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
         p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
         p.out_slot_major = (slot_major && s.train) ? 1 : 0;
-        p.pooled = pooled; p.arg = arg; p.zext = zext;
+        p.pooled = pooled; p.arg = rows_too ? arg : nullptr; p.zext = rows_too ? zext : nullptr;
         return pool_finalize(p, st);
     }
 };

@@ -66,7 +66,9 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // stays one basic block (as a run-time flag the bf16 kernels ran 10-35 % slower).
 // PIPE (fp32 path, the default; AMPNET_PW_PIPE=0 turns it off): the operands of a k step are read / computed one step ahead under the MFMAs of the
 // current step (tools/ab_pw_pipe.py compares the two forms on one box in one process).
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
+// ARG (pool epilogue only): also track the ROW of the extreme (the backward needs it; an eval forward does not -- one v_max per element instead
+// of a compare and two selects)
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true>
 __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
 {
     constexpr int CB = 32 * NT;
@@ -564,12 +566,16 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
                     if (POOL) {
                         // d is sgn(gamma) * z - z0 (signed weights): same order as z; strict compare: rows ascend, the first extreme wins
                         const float v0 = ok0 ? d0 : -__builtin_inff(), v1 = ok1 ? d1 : -__builtin_inff();
-                        const bool g0 = v0 > s_ext[t];
-                        s_ext[t] = g0 ? v0 : s_ext[t];
-                        s_arg[t] = g0 ? row0 + rr0 : s_arg[t];
-                        const bool g1 = v1 > s_ext[t];
-                        s_ext[t] = g1 ? v1 : s_ext[t];
-                        s_arg[t] = g1 ? row0 + rr0 + 1 : s_arg[t];
+                        if constexpr (ARG) {
+                            const bool g0 = v0 > s_ext[t];
+                            s_ext[t] = g0 ? v0 : s_ext[t];
+                            s_arg[t] = g0 ? row0 + rr0 : s_arg[t];
+                            const bool g1 = v1 > s_ext[t];
+                            s_ext[t] = g1 ? v1 : s_ext[t];
+                            s_arg[t] = g1 ? row0 + rr0 + 1 : s_arg[t];
+                        } else {
+                            s_ext[t] = fmaxf(s_ext[t], fmaxf(v0, v1));              // one v_max3_f32
+                        }
                     }
                 }
             }
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         }
         if (POOL) {
             a.part_max[o] = ext * sg;               // the extreme itself (max for gamma >= 0, min otherwise)
-            a.part_amax[o] = arg;
+            if (ARG) a.part_amax[o] = arg;
         }
     }
     run_n += nrows;
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     }
 }
 
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false>
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true>
 static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
@@ -709,7 +715,7 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     constexpr size_t lds_red = lds_red0 > lds_pfin ? lds_red0 : lds_pfin;
     constexpr size_t lds = lds_main + lds_red;
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
-    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE, ARG>;
     if (resident == 0) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -743,6 +749,9 @@ static int launch_pw_x(const PwGemm &a, hipStream_t st)
         // (tools/ab_pw_pipe.py); AMPNET_PW_PIPE=0 selects the plain K loop
         const char *pe = getenv("AMPNET_PW_PIPE");
         if (pe && pe[0] == '0') return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+        if constexpr (POOL) {
+            if (!a.part_amax) return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true, false>(a, st);      // extremes only (eval forward)
+        }
         return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true>(a, st);
     }
     const bool abf = a.a_bf16 != 0, zbf = a.z_bf16 != 0 && a.Z != nullptr;
@@ -799,7 +808,8 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_gemm: part_sum/part_sq must come together");
-    AMPNET_REQUIRE(!a.part_max || a.part_amax, "pw_gemm: pool partials incomplete");
+    AMPNET_REQUIRE(!a.part_max || a.part_amax || (matrix_precision() == AMPNET_PRECISION_F32 && !a.part_sum),
+                   "pw_gemm: the pool epilogue without argmax rows is the fp32 eval form (no statistics)");
     AMPNET_REQUIRE(!(a.a_bf16 || a.z_bf16) || matrix_precision() != AMPNET_PRECISION_F32, "pw_gemm: bf16 tensors need a bf16 precision mode");
     AMPNET_REQUIRE(!a.a_bf16 || a.lda % 8 == 0, "pw_gemm: bf16 A needs lda %% 8 == 0");
     int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(PoolFinalize a)
         for (int ch = 0; ch < a.chunks; ++ch) {
             const size_t o = (size_t)(q * a.chunks + ch) * a.C + c;
             const float v = a.part_max[o];
-            const int i = a.part_amax[o];
+            const int i = a.part_amax ? a.part_amax[o] : (__builtin_isinf(v) ? -1 : 0);    // no rows tracked (eval): an empty chunk holds -+inf
             if (i < 0) continue;
             if (arg < 0 || (use_max ? v > best : v < best)) {     // chunks ascend in row order: first extreme wins
                 best = v;
@@ -487,7 +487,8 @@ __global__ __launch_bounds__(1024) void pool_finalize_bn_kernel(PoolFinalize a)
 
 int pool_finalize(const PoolFinalize &a, hipStream_t st)
 {
-    AMPNET_REQUIRE(a.part_max && a.part_amax && a.pooled && (a.pfin_sum || (a.scale && a.shift)), "pool_finalize: null pointer");
+    AMPNET_REQUIRE(a.part_max && a.pooled && (a.pfin_sum ? a.part_amax != nullptr : (a.scale && a.shift)), "pool_finalize: null pointer");
+    AMPNET_REQUIRE(a.part_amax || (!a.arg), "pool_finalize: argmax rows requested but not tracked by the producer");
     AMPNET_REQUIRE(!a.out_slot_major || a.Q % a.n_slots == 0, "pool_finalize: Q %% n_slots != 0");
     if (a.pfin_sum) {
         AMPNET_REQUIRE(a.C == 256 && a.pfin_sq && a.pfin_rows && a.pfin_parts >= a.n_slots && a.pfin_parts % a.n_slots == 0 && a.pfin_gamma && a.pfin_beta && a.pfin_scale &&
