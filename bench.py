@@ -109,6 +109,8 @@ def roofline_from(rows, work_rows=None, tables=("pmc_traffic.json", "r03_pmc_cou
     if not rows:
         return None
     top = max(rows, key=lambda r: r["ms"])
+    if hbm_from_pmc and not top["name"].endswith(" bf16"):
+        hbm_from_pmc = False                 # mode 1 keeps the fp32 fused backward: its dominant kernel is priced like the fp32 step's (MFMA or HBM by intensity)
     if hbm_from_pmc:
         per_ms = top["ms"] / top["calls"]
         traffic = pmc_traffic_for(top["name"], work_rows, tables[0])

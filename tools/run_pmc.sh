@@ -32,6 +32,14 @@ if [ $rc = 0 ] && { [ $WHAT = all ] || [ $WHAT = bf16 ]; }; then
   pmc_set train_bf16_store $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 bf16_store || rc=1
   echo "bf16 rc=$rc"
 fi
+if [ $rc = 0 ] && { [ $WHAT = all ] || [ $WHAT = bf16 ] || [ $WHAT = bf16modes ]; }; then
+  # the other two opt-in precision modes: matrix-pipe busy + HBM bytes only (what their roofline objects in the bench line need)
+  for m in bf16 bf16_train; do
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/train_$m/mfma -- $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 $m > $OUT/train_$m.mfma.log 2>&1 &&
+    traffic_only train_$m $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 $m || rc=1
+  done
+  echo "bf16 modes rc=$rc"
+fi
 if [ $rc = 0 ] && { [ $WHAT = all ] || [ $WHAT = fps ]; }; then
   traffic_only fps $PY $GRAFT_REPO_ROOT/tools/prof_fps.py 2 c5 &&
   for c in stage2_256x8192_to_4096 stage1_16x16384_to_8192 stage1_256x16384_to_8192 stream_8x32768_to_8192; do
@@ -47,6 +55,10 @@ FPSARGS=""
 for c in stage2_256x8192_to_4096 stage1_16x16384_to_8192 stage1_256x16384_to_8192 stream_8x32768_to_8192; do [ -d $OUT/fps_$c ] && FPSARGS="$FPSARGS --fps-case $c=$OUT/fps_$c"; done
 [ -d $OUT/train ] && python3 profiles/pmc_traffic.py $OUT/train $OUT/pmc_traffic.json $FPSARGS
 [ -d $OUT/train_bf16_store ] && python3 profiles/pmc_traffic.py $OUT/train_bf16_store $OUT/pmc_traffic_bf16_store.json
+for m in bf16 bf16_train; do
+  [ -d $OUT/train_$m/FETCH_SIZE ] && python3 profiles/pmc_traffic.py $OUT/train_$m $OUT/pmc_traffic_$m.json
+  [ -d $OUT/train_$m/mfma ] && python3 profiles/pmc_counters.py $OUT/train_$m $OUT/pmc_counters_$m.json | tail -4
+done
 [ -f $OUT/step/r_kernel_stats.csv ] && python3 tools/step_stats.py $OUT/step/r_kernel_stats.csv 12
 # the raw per-dispatch CSVs are large: keep the summaries
 find $OUT -name "*.db" -delete; find $OUT -name "*counter_collection.csv" -size +20M -delete
