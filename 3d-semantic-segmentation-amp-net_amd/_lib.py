@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMPNET_LIB_PATH") or os.path.join(_HERE, "libampnet_hip.so")   # the override is for A/B runs of two builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPNET_ABI_VERSION 2
+#define AMPNET_ABI_VERSION 3
 
 enum {
     AMPNET_OK = 0,
