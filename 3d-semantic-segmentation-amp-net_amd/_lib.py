@@ -57,20 +57,22 @@ def lib():
     return l
 
 
-PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16_train": 2, "bf16_store": 3}
+PRECISIONS = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16_train": 2, "bf16_store": 3,
+              "f32x3": 4, "fp32_split": 4}
 
 
 def set_matrix_precision(mode):
     """'fp32' (default, exact fp32 products: the mode the parity figures hold in), 'bf16' (the forward per-point layers
     round their MFMA operands to bf16, fp32 accumulation) 'bf16_train' (forward and the fused backward of those layers) or 'bf16_store' (bf16_train + the
-    activations kept for the backward stored as bf16; include/ampnet_hip.h: ampnet_set_matrix_precision)."""
+    activations kept for the backward stored as bf16) or 'f32x3' (fp32 results from the bf16 matrix pipe: three-term bf16 split of
+    both operands of the MFMA-bound layers, six exact partial products, fp32 accumulation; include/ampnet_hip.h: ampnet_set_matrix_precision)."""
     if mode not in PRECISIONS:
         raise AmpnetError(f"unknown matrix precision {mode!r}: one of {sorted(PRECISIONS)}")
     check(lib().ampnet_set_matrix_precision(PRECISIONS[mode]), "ampnet_set_matrix_precision")
 
 
 def get_matrix_precision():
-    return {0: "fp32", 1: "bf16", 2: "bf16_train", 3: "bf16_store"}[lib().ampnet_get_matrix_precision()]
+    return {0: "fp32", 1: "bf16", 2: "bf16_train", 3: "bf16_store", 4: "f32x3"}[lib().ampnet_get_matrix_precision()]
 
 
 def check(rc, what):

@@ -136,7 +136,9 @@ int ws_tag_check(const void *ws, const char *who)
 
 extern "C" int ampnet_set_matrix_precision(int mode)
 {
-    if (mode != AMPNET_PRECISION_F32 && mode != AMPNET_PRECISION_BF16 && mode != AMPNET_PRECISION_BF16_TRAIN && mode != AMPNET_PRECISION_BF16_STORE) return ampnet::fail(AMPNET_E_ARG, "ampnet_set_matrix_precision: mode %d", mode);
+    if (mode != AMPNET_PRECISION_F32 && mode != AMPNET_PRECISION_BF16 && mode != AMPNET_PRECISION_BF16_TRAIN && mode != AMPNET_PRECISION_BF16_STORE &&
+        mode != AMPNET_PRECISION_F32_SPLIT)
+        return ampnet::fail(AMPNET_E_ARG, "ampnet_set_matrix_precision: mode %d", mode);
     ampnet::g_matrix_precision = mode;
     return AMPNET_OK;
 }

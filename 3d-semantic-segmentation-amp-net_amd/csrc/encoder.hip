@@ -182,12 +182,12 @@ struct EncRun {
         g.Z = Z; g.ldz = cout; g.cout = cout;
         if (stats) { g.part_sum = psum(region); g.part_sq = psq(region); }
         // eval forward in fp32: only the extremes are tracked (no argmax rows: nothing reads them without a backward)
-        const bool rows_too = s.train || matrix_precision() != AMPNET_PRECISION_F32;
+        const bool rows_too = s.train || !precision_is_f32();
         if (pool) { g.part_max = ws.part_max; g.part_amax = rows_too ? ws.part_amax : nullptr; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
         if (stats) {                                             // one partial per workgroup: bn_finalize in one stage (kernels.h)
             g.part_rows = prows(region);
-            g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots).lanes;
+            g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots, pw_gemm_stat_lane_cap(cin, cout)).lanes;
         }
         if (stats && pro_bn >= 0 && pend.bn == pro_bn && consumer_fin() && (cin == 64 || cin == 128)) {
             // this launch finishes its input's BatchNorm itself (kernels.h: pfin_*)
@@ -274,7 +274,7 @@ struct EncRun {
             p.pfin_scale = bs.scale; p.pfin_shift = bs.shift; p.pfin_mean = bs.mean; p.pfin_invstd = bs.invstd; p.pfin_smean = bs.smean; p.pfin_suvar = bs.suvar;
             pend.bn = -1;
         } else if (int rc = settle(); rc != AMPNET_OK) return rc;
-        const bool rows_too = s.train || matrix_precision() != AMPNET_PRECISION_F32;
+        const bool rows_too = s.train || !precision_is_f32();
         p.part_max = ws.part_max; p.part_amax = rows_too ? ws.part_amax : nullptr;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
         p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;

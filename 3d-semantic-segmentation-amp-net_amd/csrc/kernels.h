@@ -92,7 +92,8 @@ __device__ __forceinline__ StatLane stat_lane_of(int lane_id, int lanes, int n_s
     }
     return StatLane{0, 0, 1};      // not reached for lane_id < lanes
 }
-PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots);
+PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots, int max_lanes = 512);
+int pw_gemm_stat_lane_cap(int cin, int cout);      // 512, or what the split kernels of this shape hold at once (precision mode 4)
 int pw_gemm(const PwGemm &a, hipStream_t st);
 // one element of an activation tensor that is fp32 or (precision mode 3) bf16
 __device__ __forceinline__ float ld_act(const float *base, size_t elem, int bf16)
@@ -109,7 +110,10 @@ template <bool ZB> __device__ __forceinline__ float ld_act_t(const float *base, 
 // activations kept for the backward (the nine pre-BatchNorm z tensors of the encoder, z2 / z3 of the head) are stored as bf16
 inline bool z_storage_bf16() { return matrix_precision() == AMPNET_PRECISION_BF16_STORE; }
 // bf16 MFMA operands in the fused backward (modes 2 and 3)
-inline bool bwd_operands_bf16() { return matrix_precision() >= AMPNET_PRECISION_BF16_TRAIN; }
+inline bool bwd_operands_bf16() { return matrix_precision() == AMPNET_PRECISION_BF16_TRAIN || matrix_precision() == AMPNET_PRECISION_BF16_STORE; }
+// fp32 semantics: exact fp32 MFMA (mode 0) or the three-term bf16 split of the operands (mode 4: fp32 results from the bf16 pipe)
+inline bool precision_is_f32() { return matrix_precision() == AMPNET_PRECISION_F32 || matrix_precision() == AMPNET_PRECISION_F32_SPLIT; }
+inline bool precision_split() { return matrix_precision() == AMPNET_PRECISION_F32_SPLIT; }
 
 // First layers with a tiny contraction (K = 3 or 12), VALU: Z[row, 0:64] = x[row, cols] * Weff^T
 //   mode 0: Weff = W[64][3] on x[:, 0:3]                                     (T-Net conv_1 on xyz)

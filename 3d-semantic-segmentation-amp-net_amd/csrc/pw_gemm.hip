@@ -40,6 +40,53 @@ __device__ __forceinline__ bf16x8 pack_bf16(const f32x4 &lo, const f32x4 &hi)
     return o;
 }
 
+// Three-term bf16 split (precision mode AMPNET_PRECISION_F32_SPLIT): x = p1 + p2 + p3 exactly -- p1 = bf16(x), p2 = bf16(x - p1),
+// p3 = bf16(x - p1 - p2), round to nearest even each time; the residual of an fp32 number against its 8-bit head has at most 16 significant
+// bits, the second residual at most 8, so both subtractions and the last conversion are exact.  Written on PAIRS so that it compiles to
+// v_cvt_pk_bf16_f32 + (shift, and) + v_pk_add_f32 per step: 9 VALU instructions per two elements.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(const f32x2 &v)
+{
+    // as an instruction, not as two conversions: written in C the optimiser re-converts a lone element wherever only one half of the
+    // pair is needed again (the residuals below), 13 conversions per eight elements instead of 12 and scalar subtractions instead of packed
+    uint32_t p;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(v[0]), "v"(v[1]));
+    return p;
+}
+__device__ __forceinline__ f32x2 widen_pk_bf16(uint32_t p)
+{
+    return f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+__device__ __forceinline__ void split3_pair(const f32x2 &x, uint32_t &p1, uint32_t &p2, uint32_t &p3)
+{
+    p1 = cvt_pk_bf16(x);
+    const f32x2 r = x - widen_pk_bf16(p1);
+    p2 = cvt_pk_bf16(r);
+    p3 = cvt_pk_bf16(r - widen_pk_bf16(p2));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_bf16(const f32x4 &lo, const f32x4 &hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3)
+{
+    uint32_t q1[4], q2[4], q3[4];
+    split3_pair(f32x2{lo[0], lo[1]}, q1[0], q2[0], q3[0]);
+    split3_pair(f32x2{lo[2], lo[3]}, q1[1], q2[1], q3[1]);
+    split3_pair(f32x2{hi[0], hi[1]}, q1[2], q2[2], q3[2]);
+    split3_pair(f32x2{hi[2], hi[3]}, q1[3], q2[3], q3[3]);
+    p1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+    p2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+    p3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
+}
+__device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &p1, bf16x4 &p2, bf16x4 &p3)
+{
+    uint32_t q1[2], q2[2], q3[2];
+    split3_pair(f32x2{v[0], v[1]}, q1[0], q2[0], q3[0]);
+    split3_pair(f32x2{v[2], v[3]}, q1[1], q2[1], q3[1]);
+    p1 = __builtin_bit_cast(bf16x4, u32x2{q1[0], q1[1]});
+    p2 = __builtin_bit_cast(bf16x4, u32x2{q2[0], q2[1]});
+    p3 = __builtin_bit_cast(bf16x4, u32x2{q3[0], q3[1]});
+}
+
 constexpr int PW_NW = 4;   // waves per workgroup
 
 // 1 / x for x >= 1 to ~1e-16 relative: hardware estimate + two Newton steps (x0 (2 - d x0))
@@ -68,9 +115,16 @@ __device__ __forceinline__ int pidx_of(int q, int n_slots, int Q, int slot_major
 // current step (tools/ab_pw_pipe.py compares the two forms on one box in one process).
 // ARG (pool epilogue only): also track the ROW of the extreme (the backward needs it; an eval forward does not -- one v_max per element instead
 // of a compare and two selects)
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true>
-__global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
+// X3 (BF kernels, fp32 tensors; precision mode AMPNET_PRECISION_F32_SPLIT): fp32 products from the bf16 pipe -- both operands are split into three
+// bf16 terms (the weights once, while staged: three LDS images; the activations after the prologue, in registers, shared by the NT column
+// tiles) and a k step issues the six partial products a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1 per tile (each exact in fp32; the dropped
+// a2 b3 + a3 b2 + a3 b3 is below 2^-23 |a b|): 6 / 16 of the fp32 MFMA time.  NW = waves per workgroup.
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true, bool X3 = false, int NW = PW_NW, int XRT = 1>
+__global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
 {
+    static_assert(!X3 || (BF && !ABF && !ZBF && !PIPE), "the split kernels are bf16-MFMA kernels on fp32 tensors");
+    constexpr int PW_NW = NW;          // (shadows the namespace constant: every use below means this kernel's wave count)
+    constexpr int NIMG = X3 ? 3 : 1;   // bf16 images of the weight tile in LDS
     constexpr int CB = 32 * NT;
     constexpr int LDW = CIN + 4;       // fp32 weight row (floats)
     constexpr int LDB = CIN + 8;       // bf16 weight row (elements): 16-byte aligned rows, conflict-free ds_read_b128
@@ -78,7 +132,7 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sW = smem;                  // fp32: [CB][LDW]
     __bf16 *sWb = reinterpret_cast<__bf16 *>(smem);   // bf16: [CB][LDB]
-    float *sPro = BF ? smem + CB * LDB / 2 : smem + CB * LDW;     // scale[CIN], shift[CIN]
+    float *sPro = BF ? smem + NIMG * CB * LDB / 2 : smem + CB * LDW;     // scale[CIN], shift[CIN]
     float *sRed = sPro + 2 * CIN;                                  // cross-wave reduction scratch (the weights stay resident)
     double *sRun = reinterpret_cast<double *>(sRed + PW_NW * CB * 5 + PW_NW);   // [CB][2] per-workgroup running (mean, M2): a.part_rows mode
 
@@ -115,21 +169,51 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     int run_n = 0;                                                      // rows merged so far (uniform)
 
     // ---- weight staging (transposing when the matrix is k-major) ----
+    // shared weights: eight 16-byte loads in flight per thread before the first LDS write (unconditional, clamped addresses: a conditional
+    // load sits in its own basic block and the 16 trips of the old loop were 16 dependent round trips at the head of every workgroup)
+    auto put_weight = [&](int j, int k, const f32x4 &v) {
+        if (BF) {
+            if (X3) {
+                bf16x4 b1, b2, b3;
+                split3_bf16(v, b1, b2, b3);
+                *reinterpret_cast<bf16x4 *>(sWb + j * LDB + k) = b1;
+                *reinterpret_cast<bf16x4 *>(sWb + (CB + j) * LDB + k) = b2;
+                *reinterpret_cast<bf16x4 *>(sWb + (2 * CB + j) * LDB + k) = b3;
+            } else {
+                bf16x4 b;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[i];
+                *reinterpret_cast<bf16x4 *>(sWb + j * LDB + k) = b;
+            }
+        } else {
+            *reinterpret_cast<f32x4 *>(sW + j * LDW + k) = v;
+        }
+    };
     auto stage_weights = [&](int pidx) {
         if (!perwin_w) {
             const float *Wg = a.W;
-            for (int e = tid; e < CB * (CIN / 4); e += PW_NW * 64) {
-                const int j = e / (CIN / 4), k4 = e % (CIN / 4);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cb0 + j < a.cout) v = *reinterpret_cast<const f32x4 *>(Wg + (size_t)(cb0 + j) * a.ldw + 4 * k4);
-                if (POOL && a.pool_gamma && cb0 + j < a.cout && a.pool_gamma[cb0 + j] < 0.f) v = -v;     // z' = sgn(gamma) z: the pool tracks max z'
-                if (BF) {
-                    bf16x4 b;
+            constexpr int TOT = CB * (CIN / 4), SU = 8;
+            const bool flip = POOL && a.pool_gamma != nullptr;
+            for (int e0 = tid; e0 < TOT; e0 += PW_NW * 64 * SU) {
+                f32x4 v[SU];
+                float gs[SU];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[i];
-                    *reinterpret_cast<bf16x4 *>(sWb + j * LDB + 4 * k4) = b;
-                } else {
-                    *reinterpret_cast<f32x4 *>(sW + j * LDW + 4 * k4) = v;
+                for (int u = 0; u < SU; ++u) {
+                    const int e = e0 + u * PW_NW * 64;
+                    const int j = (e < TOT ? e : 0) / (CIN / 4), k4 = e % (CIN / 4);
+                    const int jj = cb0 + j < a.cout ? cb0 + j : 0;
+                    v[u] = *reinterpret_cast<const f32x4 *>(Wg + (size_t)jj * a.ldw + 4 * k4);
+                    gs[u] = flip ? a.pool_gamma[jj] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int e = e0 + u * PW_NW * 64;
+                    if (e >= TOT) continue;
+                    const int j = e / (CIN / 4), k4 = e % (CIN / 4);
+                    f32x4 w = v[u];
+                    if (cb0 + j >= a.cout) w = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (gs[u] < 0.f) w = -w;                                 // z' = sgn(gamma) z: the pool tracks max z'
+                    put_weight(j, 4 * k4, w);
                 }
             }
         } else {
@@ -137,52 +221,70 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             for (int e = tid; e < CIN * CB; e += PW_NW * 64) {
                 const int k = e / CB, j = e % CB;
                 const float v = (cb0 + j < a.cout) ? Wg[(size_t)k * a.cout + cb0 + j] : 0.f;
-                if (BF) sWb[j * LDB + k] = (__bf16)v;
+                if (BF && X3) {
+                    const __bf16 b1 = (__bf16)v;
+                    const float r1 = v - (float)b1;
+                    const __bf16 b2 = (__bf16)r1;
+                    sWb[j * LDB + k] = b1;
+                    sWb[(CB + j) * LDB + k] = b2;
+                    sWb[(2 * CB + j) * LDB + k] = (__bf16)(r1 - (float)b2);
+                } else if (BF) sWb[j * LDB + k] = (__bf16)v;
                 else sW[j * LDW + k] = v;
             }
         }
     };
+
+    // Consumer-side finalize of the INPUT's BatchNorm (kernels.h: pfin_*): the input BatchNorm's constants of this workgroup's slot from the
+    // producer's per-workgroup partials in ONE memory round trip -- thread (gq, cq) takes the partials gq, gq + G, ... of the slot for the four
+    // channels 4 cq .. 4 cq + 3 (16-byte loads, a batch of eight in flight).  The FIRST batch (all of them for <= 64 partials per slot) is
+    // requested BEFORE the weight tile is staged, so that its round trip runs under the staging instead of after it (round 3 had it behind:
+    // a dependent trip + the merge + two barriers in front of the first MFMA of every workgroup, +3 % on the pooled GEMM).
+    constexpr int CQ = CIN / 4;                                    // channel quads
+    constexpr int GW = 64 / CQ >= 1 ? 64 / CQ : 1;                 // groups per wave (2 at 128 channels, 4 at 64)
+    constexpr int G = GW * PW_NW > 8 ? 8 : GW * PW_NW;             // groups in all
+    constexpr int WV = G / GW;                                     // waves that take part
+    static_assert(CQ <= 64 && G % GW == 0, "a wave holds whole groups");
+    const bool pfin = PRO && a.pfin_sum != nullptr;
+    const int cq = lane % CQ, gq = wave * GW + lane / CQ;
+    const int per_slot_parts = pfin ? a.pfin_parts / a.n_slots : 0;
+    f32x4 fv[8], fw[8];
+    int frw[8];
+    auto pfin_load = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k0 + G * u;
+            const int idx = my_slot + (kk < per_slot_parts ? kk : 0) * a.n_slots;
+            frw[u] = kk < per_slot_parts ? a.pfin_rows[idx] : 0;
+            fv[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sum + (size_t)idx * CIN + 4 * cq);
+            fw[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sq + (size_t)idx * CIN + 4 * cq);
+        }
+    };
+    if (PRO) {
+        if (pfin && gq < G && gq < per_slot_parts) pfin_load(gq);
+    }
     if (!perwin_w) stage_weights(0);
 
     int staged_slot = -1;
-    if (PRO && a.pfin_sum) {
-        // The input BatchNorm's constants of this workgroup's slot from the producer's per-workgroup partials (kernels.h: pfin_*), in ONE
-        // memory round trip: thread (gq, cq) takes the partials gq, gq + G, ... of the slot for the four channels 4 cq .. 4 cq + 3 (16-byte
-        // loads, all of a batch of eight in flight), sums n, n mean and M2 + n mean^2 in double, the groups of a wave are folded by
-        // shuffles and the waves through LDS in wave order: fixed order, bitwise reproducible.  M2 = sum (M2_i + n_i mean_i^2) - N mean^2 in
-        // double is exact to ~1e-10 of M2 for fp32 partials unless |mean| > 1e3 sigma.
-        constexpr int CQ = CIN / 4;                                    // channel quads
-        constexpr int GW = 64 / CQ >= 1 ? 64 / CQ : 1;                 // groups per wave (2 at 128 channels, 4 at 64)
-        constexpr int G = GW * PW_NW > 8 ? 8 : GW * PW_NW;             // groups in all
-        constexpr int WV = G / GW;                                     // waves that take part
-        static_assert(CQ <= 64 && G % GW == 0, "a wave holds whole groups");
+    if (PRO && pfin) {
+        // sums of n, n mean and M2 + n mean^2 in double, the groups of a wave are folded by shuffles and the waves through LDS in wave order:
+        // fixed order, bitwise reproducible.  M2 = sum (M2_i + n_i mean_i^2) - N mean^2 in double is exact to ~1e-10 of M2 for fp32 partials
+        // unless |mean| > 1e3 sigma.
         double *rsm = reinterpret_cast<double *>(sRed);                // [WV][CIN] sum n mean, then [WV][CIN] sum (M2 + n mean^2), [WV] n
         double *rsq = rsm + WV * CIN, *rnn = rsq + WV * CIN;
-        const int cq = lane % CQ, gq = wave * GW + lane / CQ;
-        const int per_slot_parts = a.pfin_parts / a.n_slots;
         double sn = 0.0, sm[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
         if (gq < G) {
             for (int k0 = gq; k0 < per_slot_parts; k0 += G * 8) {
-                f32x4 v[8], w[8];
-                int rw[8];
+                if (k0 != gq) pfin_load(k0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int kk = k0 + G * u;
-                    const int idx = my_slot + (kk < per_slot_parts ? kk : 0) * a.n_slots;
-                    rw[u] = kk < per_slot_parts ? a.pfin_rows[idx] : 0;
-                    v[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sum + (size_t)idx * CIN + 4 * cq);
-                    w[u] = *reinterpret_cast<const f32x4 *>(a.pfin_sq + (size_t)idx * CIN + 4 * cq);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (rw[u] > 0) {
-                        const double nn = (double)rw[u];
+                    if (frw[u] > 0) {
+                        const double nn = (double)frw[u];
                         sn += nn;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const double m = (double)v[u][i];
+                            const double m = (double)fv[u][i];
                             sm[i] += nn * m;
-                            sq[i] += (double)w[u][i] + nn * m * m;
+                            sq[i] += (double)fw[u][i] + nn * m * m;
                         }
                     }
                 }
@@ -304,6 +406,162 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
         init_v[t] = bias_v[t];
     }
 
+    // The epilogue of one finished 32-row tile (accumulators `acc`, rows row0 .. row0 + valid - 1).  first: the wave's first tile of this block
+    // of rows (its row 0 becomes the shift z0 of the statistics); fresh: the accumulators started at the bias (z0 was not known yet).
+    auto finish_tile = [&](f32x16 (&acc)[NT], const int row0, const int valid, const bool first, const bool fresh) {
+        // ---- epilogue: lane = output channel, registers = 16 rows; predicated, no branch between elements ----
+        if (do_stats) {
+            if (first) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float z0 = __shfl(acc[t][0], r);            // row0 + 0 lives in lane r, register 0 (bias included)
+                    s_z0[t] = z0;
+                    init_v[t] = bias_v[t] - z0;
+                }
+            }
+            if (fresh) {                                   // this tile's accumulators started at the bias, not at bias - z0
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] -= s_z0[t];
+            }
+            s_cnt += valid;
+        }
+        // FULL: all 32 rows of the tile exist (every tile but a window's last): no row predicate at all.  STATS is a compile-time
+        // copy of do_stats: as a run-time flag the compiler turned every `s_sum += d` into an add AND a select
+        auto epilogue = [&](auto full_tag, auto stats_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr bool STATS = decltype(stats_tag)::value;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = cb0 + 32 * t + r;
+                // split kernels: whole column blocks only and the store decided at compile time (the pooled layers never store) -- as run-time
+                // lane conditions these are an exec-mask branch around every pair of elements, stores or not
+                const bool cok = X3 || col < a.cout;
+                const float z0 = STATS ? s_z0[t] : 0.f;
+                float *zp = a.Z + (size_t)row0 * a.ldz + col;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int rr0 = (e & 3) + 8 * (e >> 2) + 4 * h;       // e even: rows rr0 and rr0 + 1
+                    const bool ok0 = FULL || rr0 < valid, ok1 = FULL || rr0 + 1 < valid;
+                    const float d0 = acc[t][e], d1 = acc[t][e + 1];
+                    if ((X3 ? !POOL : do_store) && cok) {
+                        if (BF && ZBF) {
+                            if (ok0) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0) * a.ldz + col] = (__bf16)(d0 + z0);
+                            if (ok1) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0 + 1) * a.ldz + col] = (__bf16)(d1 + z0);
+                        } else {
+                            if (ok0) zp[(size_t)rr0 * a.ldz] = d0 + z0;
+                            if (ok1) zp[(size_t)(rr0 + 1) * a.ldz] = d1 + z0;
+                        }
+                    }
+                    if (STATS) {
+                        const f32x2 d2 = {ok0 ? d0 : 0.f, ok1 ? d1 : 0.f};
+                        s_sum2[t] += d2;
+                        s_sq2[t] = __builtin_elementwise_fma(d2, d2, s_sq2[t]);
+                    }
+                    if (POOL) {
+                        // d is sgn(gamma) * z - z0 (signed weights): same order as z; strict compare: rows ascend, the first extreme wins
+                        const float v0 = ok0 ? d0 : -__builtin_inff(), v1 = ok1 ? d1 : -__builtin_inff();
+                        if constexpr (ARG) {
+                            const bool g0 = v0 > s_ext[t];
+                            s_ext[t] = g0 ? v0 : s_ext[t];
+                            s_arg[t] = g0 ? row0 + rr0 : s_arg[t];
+                            const bool g1 = v1 > s_ext[t];
+                            s_ext[t] = g1 ? v1 : s_ext[t];
+                            s_arg[t] = g1 ? row0 + rr0 + 1 : s_arg[t];
+                        } else {
+                            s_ext[t] = fmaxf(s_ext[t], fmaxf(v0, v1));              // one v_max3_f32
+                        }
+                    }
+                }
+            }
+        };
+        if (do_stats) {
+            if (valid == 32) epilogue(std::true_type{}, std::true_type{});
+            else epilogue(std::false_type{}, std::true_type{});
+        } else {
+            if (valid == 32) epilogue(std::true_type{}, std::false_type{});
+            else epilogue(std::false_type{}, std::false_type{});
+        }
+    };
+
+    if constexpr (X3) {
+        // ---- split kernels: ONE wave per SIMD with the whole register file (512 per lane) and 64 rows per wave: two 32-row sub-tiles share
+        // every weight fragment read from LDS, and there is room to keep a k step's operands ahead of its MFMAs ----
+        static_assert(PRO != 2 && NBLK >= 1, "the split kernels have no dropout prologue");
+        constexpr int RT = XRT;
+        const int nst = (nrows + 31) / 32;                   // 32-row sub-tiles of this block of rows
+        // Two waves per SIMD (8-wave workgroup, one per CU): a wave's step is a VALU phase (BatchNorm + ReLU, the three-term split: ~50
+        // instructions) and an MFMA phase (6 * NT = 24 MFMAs, 768 cycles of the SIMD's matrix pipe); the partner wave fills the pipe during the
+        // VALU phase and the epilogue.  The A operand of a k step (16 k of 32 rows: two 16-byte loads per lane) is requested THREE steps ahead
+        // into one of four register buffers addressed by step parity mod 4 (8 steps per tile: a tile starts at buffer 0 again, no copies):
+        // with one 32-k block ahead (two steps) the waves spent 30 % of their time in s_waitcnt vmcnt (rocprofv3 SQ_WAIT_INST_ANY).
+        static_assert(RT == 1 && (2 * NBLK) % 4 == 0, "step parity addresses the four A buffers");
+        constexpr int NSTEP = 2 * NBLK, AHEAD = 3;
+        f32x4 xa[4][2];
+        auto load_step = [&](f32x4 (&dst)[2], int st_, int step_) {
+            // rows past the block's end re-read its last row: their products are never used
+            const int row = min(row_begin + st_ * 32 + r, row_end - 1);
+            const float *ap = a.A + (size_t)row * a.lda + 16 * step_ + 8 * h;
+            dst[0] = *reinterpret_cast<const f32x4 *>(ap);
+            dst[1] = *reinterpret_cast<const f32x4 *>(ap + 4);
+        };
+        int st0 = wave;
+        if (st0 < nst) {
+#pragma unroll
+            for (int p = 0; p < AHEAD; ++p) load_step(xa[p], st0, p);
+        }
+        for (; st0 < nst; st0 += PW_NW) {
+            const bool fresh0 = st0 == wave;
+            const bool more = st0 + PW_NW < nst;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] = init_v[t];
+#pragma unroll
+            for (int sp = 0; sp < NSTEP; ++sp) {
+                // request step sp + AHEAD (of this tile, or of the wave's next one)
+                // (unconditional: behind a branch the wait counts below turn conservative, vmcnt(0) at the tile's end; the last tile re-reads itself)
+                if (sp + AHEAD < NSTEP) load_step(xa[(sp + AHEAD) & 3], st0, sp + AHEAD);
+                else load_step(xa[(sp + AHEAD) & 3], more ? st0 + PW_NW : st0, sp + AHEAD - NSTEP);
+                __builtin_amdgcn_sched_barrier(0);       // the prefetch stays HERE (in the unrolled body the scheduler sinks loads to their use)
+                const int k0 = 16 * sp + 8 * h;
+                f32x4 lo = xa[sp & 3][0], hi = xa[sp & 3][1];
+                if (PRO) {
+                    const f32x4 sc0 = *reinterpret_cast<const f32x4 *>(sPro + k0), sc1 = *reinterpret_cast<const f32x4 *>(sPro + k0 + 4);
+                    const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0), sh1 = *reinterpret_cast<const f32x4 *>(sPro + CIN + k0 + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = fmaxf(fmaf(lo[i], sc0[i], sh0[i]), 0.f);
+                        hi[i] = fmaxf(fmaf(hi[i], sc1[i], sh1[i]), 0.f);
+                    }
+                }
+                bf16x8 a1, a2, a3, b1[NT], b2[NT], b3[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    b1[t] = *reinterpret_cast<const bf16x8 *>(sWb + (32 * t + r) * LDB + k0);
+                    b2[t] = *reinterpret_cast<const bf16x8 *>(sWb + (CB + 32 * t + r) * LDB + k0);
+                    b3[t] = *reinterpret_cast<const bf16x8 *>(sWb + (2 * CB + 32 * t + r) * LDB + k0);
+                }
+                split3_bf16(lo, hi, a1, a2, a3);
+                // six exact partial products per tile; one accumulator takes its six back to back (a dependent chain of this MFMA issues at
+                // full rate)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[t], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[t], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[t], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[t], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[t], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[t], acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // steps do not mix: the unrolled body would otherwise hoist reads for several steps and spill
+            }
+            const int row0 = row_begin + st0 * 32;
+            finish_tile(acc, row0, min(32, row_end - row0), fresh0, fresh0);
+        }
+    } else {
     const int ntiles = (nrows + 31) / 32;
     // A fragments: blocks of 4 j (= 32 k = one 128-byte line per row), the next block prefetched in registers
     // while the current one feeds 16 * NT MFMAs.  The prefetch runs across tile boundaries.
@@ -519,74 +777,8 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
             }
         }
 
-        // ---- epilogue: lane = output channel, registers = 16 rows; predicated, no branch between elements ----
-        if (do_stats) {
-            if (tile == wave) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float z0 = __shfl(acc[t][0], r);            // row0 + 0 lives in lane r, register 0 (bias included)
-                    s_z0[t] = z0;
-                    init_v[t] = bias_v[t] - z0;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[t][e] -= z0;
-                }
-            }
-            s_cnt += valid;
-        }
-        // FULL: all 32 rows of the tile exist (every tile but a window's last): no row predicate at all.  STATS is a compile-time
-        // copy of do_stats: as a run-time flag the compiler turned every `s_sum += d` into an add AND a select
-        auto epilogue = [&](auto full_tag, auto stats_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            constexpr bool STATS = decltype(stats_tag)::value;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = cb0 + 32 * t + r;
-                const bool cok = col < a.cout;
-                const float z0 = STATS ? s_z0[t] : 0.f;
-                float *zp = a.Z + (size_t)row0 * a.ldz + col;
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const int rr0 = (e & 3) + 8 * (e >> 2) + 4 * h;       // e even: rows rr0 and rr0 + 1
-                    const bool ok0 = FULL || rr0 < valid, ok1 = FULL || rr0 + 1 < valid;
-                    const float d0 = acc[t][e], d1 = acc[t][e + 1];
-                    if (do_store && cok) {
-                        if (BF && ZBF) {
-                            if (ok0) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0) * a.ldz + col] = (__bf16)(d0 + z0);
-                            if (ok1) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0 + 1) * a.ldz + col] = (__bf16)(d1 + z0);
-                        } else {
-                            if (ok0) zp[(size_t)rr0 * a.ldz] = d0 + z0;
-                            if (ok1) zp[(size_t)(rr0 + 1) * a.ldz] = d1 + z0;
-                        }
-                    }
-                    if (STATS) {
-                        const f32x2 d2 = {ok0 ? d0 : 0.f, ok1 ? d1 : 0.f};
-                        s_sum2[t] += d2;
-                        s_sq2[t] = __builtin_elementwise_fma(d2, d2, s_sq2[t]);
-                    }
-                    if (POOL) {
-                        // d is sgn(gamma) * z - z0 (signed weights): same order as z; strict compare: rows ascend, the first extreme wins
-                        const float v0 = ok0 ? d0 : -__builtin_inff(), v1 = ok1 ? d1 : -__builtin_inff();
-                        if constexpr (ARG) {
-                            const bool g0 = v0 > s_ext[t];
-                            s_ext[t] = g0 ? v0 : s_ext[t];
-                            s_arg[t] = g0 ? row0 + rr0 : s_arg[t];
-                            const bool g1 = v1 > s_ext[t];
-                            s_ext[t] = g1 ? v1 : s_ext[t];
-                            s_arg[t] = g1 ? row0 + rr0 + 1 : s_arg[t];
-                        } else {
-                            s_ext[t] = fmaxf(s_ext[t], fmaxf(v0, v1));              // one v_max3_f32
-                        }
-                    }
-                }
-            }
-        };
-        if (do_stats) {
-            if (valid == 32) epilogue(std::true_type{}, std::true_type{});
-            else epilogue(std::false_type{}, std::true_type{});
-        } else {
-            if (valid == 32) epilogue(std::true_type{}, std::false_type{});
-            else epilogue(std::false_type{}, std::false_type{});
-        }
+        finish_tile(acc, row0, valid, tile == wave, tile == wave);
+    }
     }
 
     if (!do_stats && !POOL) continue;
@@ -705,24 +897,25 @@ __global__ __launch_bounds__(PW_NW * 64, 2) void pw_gemm_kernel(PwGemm a)
     }
 }
 
-template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true>
+template <int CIN, int NT, int PRO, bool POOL, bool BF, bool ABF = false, bool ZBF = false, bool PIPE = false, bool ARG = true, bool X3 = false, int NW = PW_NW, int XRT = 1>
 static int launch_pw_y(const PwGemm &a, hipStream_t st)
 {
     constexpr int CB = 32 * NT;
-    constexpr size_t lds_main = BF ? (size_t)CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
-    constexpr size_t lds_red0 = (size_t)(PW_NW * CB * 5 + PW_NW) * sizeof(float) + (size_t)CB * 2 * sizeof(double);   // + sRun
+    constexpr size_t lds_main = BF ? (size_t)(X3 ? 3 : 1) * CB * (CIN + 8) * 2 + (size_t)2 * CIN * sizeof(float) : (size_t)(CB * (CIN + 4) + 2 * CIN) * sizeof(float);
+    constexpr size_t lds_red0 = (size_t)(NW * CB * 5 + NW) * sizeof(float) + (size_t)CB * 2 * sizeof(double);   // + sRun
     constexpr size_t lds_pfin = (size_t)(4 * 2 * CIN + 8) * sizeof(double);                   // scratch of the consumer-side BatchNorm finalize (same region)
     constexpr size_t lds_red = lds_red0 > lds_pfin ? lds_red0 : lds_pfin;
     constexpr size_t lds = lds_main + lds_red;
+    static_assert(lds <= 160 * 1024, "LDS budget of a CU");
     static int resident = 0;           // workgroups the device holds at once (CUs x occupancy), measured once per instantiation
-    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE, ARG>;
+    auto kern = pw_gemm_kernel<CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE, ARG, X3, NW, XRT>;
     if (resident == 0) {
         if (lds > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_gemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         }
         int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), PW_NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident = per_cu * cus;
     }
@@ -734,25 +927,39 @@ static int launch_pw_y(const PwGemm &a, hipStream_t st)
     if (a.part_rows) lanes = cdiv(a.stat_lanes, 8) * 8;                // per-workgroup statistics: the plan fixes the lanes (pw_gemm_stat_plan)
     dim3 grid((unsigned)(lanes * ncb));
     char name[64];
-    snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", BF ? " bf16" : "");
+    snprintf(name, sizeof(name), "pw_gemm<%d,%d>%s%s%s", CIN, 32 * NT, a.Z ? "+store" : "", a.part_max ? "+pool" : "", X3 ? " x3" : (BF ? " bf16" : ""));
     const double rows = (double)a.rows_hint;
     ProfScope prof(name, 2.0 * rows * CIN * a.cout, rows * ((a.a_bf16 ? 2.0 : 4.0) * (double)CIN * cdiv(a.cout, CB) + (a.Z ? (a.z_bf16 ? 2.0 : 4.0) * a.cout : 0.0)), st);
-    hipLaunchKernelGGL(kern, grid, dim3(PW_NW * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, a);
     return check_launch("pw_gemm_kernel");
 }
+
+// the split kernels exist for the MFMA-bound shape (128 inputs, > 64 output columns per block) of the real point layers
+constexpr int PW_X3_NW = 8;     // two waves per SIMD, one workgroup per CU (three bf16 images of the weight tile: 104 KB of LDS)
+template <int CIN, int NT, int PRO, bool POOL>
+static constexpr bool pw_x3_built = CIN == 128 && NT == 4 && PRO == 1;
 
 template <int CIN, int NT, int PRO, bool POOL>
 static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
-    if (matrix_precision() == AMPNET_PRECISION_F32) {
+    if (precision_is_f32()) {
+        if constexpr (pw_x3_built<CIN, NT, PRO, POOL>) {
+            if (precision_split() && !a.w_win_stride && a.uniform_rows == 0 && a.cout % (32 * NT) == 0 && (POOL || a.Z)) {       // the real point layers (not the T-Net FC rows)
+                if constexpr (POOL) {
+                    if (!a.part_amax) return launch_pw_y<CIN, NT, PRO, POOL, true, false, false, false, false, true, PW_X3_NW>(a, st);
+                }
+                return launch_pw_y<CIN, NT, PRO, POOL, true, false, false, false, true, true, PW_X3_NW>(a, st);
+            }
+        }
         // one-step-ahead operand reads: 2.3 % on the train step, 5.9 % on the eval forward in an interleaved same-box A/B
         // (tools/ab_pw_pipe.py); AMPNET_PW_PIPE=0 selects the plain K loop
         const char *pe = getenv("AMPNET_PW_PIPE");
-        if (pe && pe[0] == '0') return launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
+        const bool pipe = !(pe && pe[0] == '0');
         if constexpr (POOL) {
-            if (!a.part_amax) return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true, false>(a, st);      // extremes only (eval forward)
+            if (!a.part_amax)                                           // extremes only (eval forward): the ARG = false epilogue never touches part_amax
+                return pipe ? launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true, false>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false, false, false, false, false>(a, st);
         }
-        return launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true>(a, st);
+        return pipe ? launch_pw_y<CIN, NT, PRO, POOL, false, false, false, true>(a, st) : launch_pw_y<CIN, NT, PRO, POOL, false>(a, st);
     }
     const bool abf = a.a_bf16 != 0, zbf = a.z_bf16 != 0 && a.Z != nullptr;
     if (abf && zbf) return launch_pw_y<CIN, NT, PRO, POOL, true, true, true>(a, st);
@@ -782,16 +989,23 @@ static int launch_pw(const PwGemm &a, hipStream_t st)
 
 // lanes per slot for the per-workgroup statistics of a layer with one column block per row block: at most 512 workgroups (two per CU of
 // the MI355X; on another part the surplus queues, the result does not change), never more than a slot has blocks of rows
-PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots)
+PwStatPlan pw_gemm_stat_plan(int Q, int chunks, int n_slots, int max_lanes)
 {
     PwStatPlan p;
     const long items = (long)Q * chunks;                      // blocks of rows in all
-    int lanes = items < 512 ? (int)items : 512;
+    int lanes = items < max_lanes ? (int)items : max_lanes;
     if (lanes < n_slots) lanes = n_slots;                     // every slot needs a lane (one that finds no rows writes an empty partial)
     p.lanes = lanes;
     p.parts = cdiv(lanes, n_slots) * n_slots;
     p.direct = cdiv(Q, n_slots) * chunks == 1;                // every slot is ONE block of rows: the workgroup's statistics are the slot's
     return p;
+}
+
+// the split kernels hold one workgroup per CU (three weight images in LDS): a persistent grid is 256 workgroups over the column blocks
+int pw_gemm_stat_lane_cap(int cin, int cout)
+{
+    if (precision_split() && cin == 128 && cout > 64 && cout % 128 == 0) return 256 / (cout / 128);
+    return 512;
 }
 
 int pw_gemm(const PwGemm &a, hipStream_t st)
@@ -808,9 +1022,9 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
     AMPNET_REQUIRE(a.lda % 4 == 0 && (a.w_win_stride != 0 || a.ldw % 4 == 0), "pw_gemm: lda/ldw must be multiples of 4");
     AMPNET_REQUIRE(a.n_slots >= 1 && (!a.perwin_slot_major || a.Q % a.n_slots == 0), "pw_gemm: Q %% n_slots != 0");
     AMPNET_REQUIRE((a.part_sum == nullptr) == (a.part_sq == nullptr), "pw_gemm: part_sum/part_sq must come together");
-    AMPNET_REQUIRE(!a.part_max || a.part_amax || (matrix_precision() == AMPNET_PRECISION_F32 && !a.part_sum),
+    AMPNET_REQUIRE(!a.part_max || a.part_amax || (precision_is_f32() && !a.part_sum),
                    "pw_gemm: the pool epilogue without argmax rows is the fp32 eval form (no statistics)");
-    AMPNET_REQUIRE(!(a.a_bf16 || a.z_bf16) || matrix_precision() != AMPNET_PRECISION_F32, "pw_gemm: bf16 tensors need a bf16 precision mode");
+    AMPNET_REQUIRE(!(a.a_bf16 || a.z_bf16) || !precision_is_f32(), "pw_gemm: bf16 tensors need a bf16 precision mode");
     AMPNET_REQUIRE(!a.a_bf16 || a.lda % 8 == 0, "pw_gemm: bf16 A needs lda %% 8 == 0");
     int nt = a.cout > 64 ? 4 : (a.cout > 32 ? 2 : 1);
     // tiny problems (the T-Net FC layers: nine blocks of 64 rows): narrower column blocks = more workgroups, each staging a

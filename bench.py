@@ -535,7 +535,7 @@ def main():
     ap.add_argument("--kernels", type=int, default=8, help="how many kernels to list in the JSON line")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check only: no GPU work (tests/test_dp_cpu.py)")
     ap.add_argument("--probe", choices=["syncbn"], default=None, help="internal: child-process probes of the default run")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train", "bf16_store"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16_train", "bf16_store", "f32x3"], default=os.environ.get("AMPNET_PRECISION", "fp32"),
                     help="MFMA operand precision: fp32 (headline), bf16 = forward per-point layers, bf16_train = forward + fused backward (fp32 accumulate)")
     args = ap.parse_args()
 
@@ -739,7 +739,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16 forward MFMA operands, f32 accumulate / statistics / backward",
                                           "bf16_train": "bf16 MFMA operands (forward + fused backward), f32 accumulate / statistics / tensors",
-                                          "bf16_store": "bf16 MFMA operands + bf16 stored activations, f32 accumulate / statistics / gradients"}[args.precision], "data": "synthetic",
+                                          "bf16_store": "bf16 MFMA operands + bf16 stored activations, f32 accumulate / statistics / gradients",
+                                          "f32x3": "f32 via 3xbf16 split operands (six exact bf16 partial products per product on the MFMA-bound layers), f32 accumulate, f32 tensors"}[args.precision], "data": "synthetic",
             "config": {"workload": ("AMP-Net full train step (fwd+loss+bwd+2xAdam)" if mode == "train" else "AMP-Net forward only (eval, logits+argmax)")
                        + f", {B} samples x {N_WIN} windows x {N_POINTS} pts x 9 feats per GPU", "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": f"dp{world}",

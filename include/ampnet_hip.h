@@ -335,6 +335,15 @@ int ampnet_set_collective(ampnet_collective_fn fn, void *ctx, int rank, int worl
  * workspace that holds no train-mode forward of this process, instead of misreading the saved activations (tests/test_bf16_gpu.py).
  * Modes 0 .. 2 share the fp32 tape: a backward in one of them may follow a forward in another.                                   */
 #define AMPNET_PRECISION_BF16_STORE 3
+/* AMPNET_PRECISION_F32_SPLIT ("f32x3"): fp32 results from the bf16 matrix pipe.  Every operand of the MFMA-bound per-point products
+ * (the 128 -> 256 pooled layers and the 128 -> 128 layer of the forward; the Gram-form and the dense 128 x 128 fused backward) is split
+ * into three bf16 terms a = a1 + a2 + a3 (three successive round-to-nearest roundings: the sum is the fp32 value exactly) and the
+ * product is formed from six v_mfma_f32_32x32x16_bf16 instructions (a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1: each partial product
+ * of two bf16 numbers is exact in fp32, the three dropped terms are below 2^-23 |a b|), accumulated in fp32: 6 / 16 of the fp32 MFMA
+ * time at fp32 accuracy.  Tensors in HBM, BatchNorm statistics, prologues, epilogues and every other kernel are those of
+ * AMPNET_PRECISION_F32 (same tape: a backward in one of the two modes may follow a forward in the other).  The parity tests of the
+ * fp32 path run in this mode with the same bars (tests/conftest.py: AMPNET_TEST_PRECISION).                                       */
+#define AMPNET_PRECISION_F32_SPLIT 4
 int ampnet_set_matrix_precision(int mode);
 int ampnet_get_matrix_precision(void);
 
