@@ -27,6 +27,7 @@ struct BnSlot {              // per-layer derived arrays, each [n_slots, C]
 struct EncShape {
     int Q, n_slots, R, max_rows, train;
     int chunk_rows, chunks;            // point layers
+    int x_chunk_rows, x_chunks;        // point layers that run on the split kernels (precision mode 4): a block of rows is one wave's
     int fc_rows, fc_chunk_rows, fc_chunks;   // T-Net FC layers: n_slots windows of Q / n_slots rows
 };
 

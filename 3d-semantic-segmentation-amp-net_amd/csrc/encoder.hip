@@ -29,6 +29,8 @@ EncShape enc_shape(int Q, int n_slots, int R, int max_rows, int train)
     s.train = train;
     s.chunk_rows = 512;
     s.chunks = cdiv(max_rows, s.chunk_rows);
+    s.x_chunk_rows = 128;
+    s.x_chunks = cdiv(max_rows, s.x_chunk_rows);
     s.fc_rows = Q / n_slots;
     s.fc_chunk_rows = 128;
     s.fc_chunks = cdiv(s.fc_rows, s.fc_chunk_rows);
@@ -91,7 +93,8 @@ void enc_carve(const EncShape &s, void *base, EncWs &ws)
     ws.zext_c = c.take<float>(Q * 256);
     ws.part_rows = c.take<int>(2 * enc_fwd_part_region_rows(s));
     ws.merge = c.take<float>(bn_finalize_merge_floats(s.n_slots, 256));     // two-stage bn_finalize scratch
-    const size_t np = Q * (size_t)(s.chunks > s.fc_chunks ? s.chunks : s.fc_chunks) * 256;
+    const int pchunks = s.x_chunks > s.chunks ? s.x_chunks : s.chunks;        // sized for either kernel family (the precision mode may change between calls)
+    const size_t np = Q * (size_t)(pchunks > s.fc_chunks ? pchunks : s.fc_chunks) * 256;
     // the fused backward indexes its BatchNorm sums by workgroup (<= 256 + n_slots of them) + one row per window
     const size_t two_regions = 2 * enc_bwd_part_region_floats(s);
     size_t np_bwd = np + (size_t)(320 + s.n_slots) * 256 > two_regions ? np + (size_t)(320 + s.n_slots) * 256 : two_regions;
@@ -140,6 +143,7 @@ struct EncRun {
     float *psum(int r) const { return ws.part_sum + (size_t)r * enc_fwd_part_region_floats(s); }
     float *psq(int r) const { return ws.part_sq + (size_t)r * enc_fwd_part_region_floats(s); }
     int *prows(int r) const { return ws.part_rows + (size_t)r * enc_fwd_part_region_rows(s); }
+    static bool split_layer(int cin, int cout) { return pw_gemm_stat_lane_cap(cin, cout) != 512; }     // this layer runs on the split kernels
     bool consumer_fin() const
     {
         static const bool off = [] { const char *v = getenv("AMPNET_FWD_FIN_IN_KERNEL"); return v && v[0] == '0'; }();
@@ -185,9 +189,10 @@ struct EncRun {
         const bool rows_too = s.train || !precision_is_f32();
         if (pool) { g.part_max = ws.part_max; g.part_amax = rows_too ? ws.part_amax : nullptr; g.pool_gamma = bnp[pool_bn].gamma; }
         g.win_off = win_off; g.Q = s.Q; g.chunk_rows = s.chunk_rows; g.chunks = s.chunks; g.rows_hint = s.R;
+        if (split_layer(cin, cout)) { g.chunk_rows = s.x_chunk_rows; g.chunks = s.x_chunks; }     // one wave per block of rows (pw_gemm.hip)
         if (stats) {                                             // one partial per workgroup: bn_finalize in one stage (kernels.h)
             g.part_rows = prows(region);
-            g.stat_lanes = pw_gemm_stat_plan(s.Q, s.chunks, g.n_slots, pw_gemm_stat_lane_cap(cin, cout)).lanes;
+            g.stat_lanes = pw_gemm_stat_plan(s.Q, g.chunks, g.n_slots, pw_gemm_stat_lane_cap(cin, cout)).lanes;
         }
         if (stats && pro_bn >= 0 && pend.bn == pro_bn && consumer_fin() && (cin == 64 || cin == 128)) {
             // this launch finishes its input's BatchNorm itself (kernels.h: pfin_*)
@@ -277,7 +282,7 @@ struct EncRun {
         const bool rows_too = s.train || !precision_is_f32();
         p.part_max = ws.part_max; p.part_amax = rows_too ? ws.part_amax : nullptr;
         p.scale = ws.bn[bn].scale; p.shift = ws.bn[bn].shift;
-        p.Q = s.Q; p.chunks = s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
+        p.Q = s.Q; p.chunks = split_layer(128, 256) ? s.x_chunks : s.chunks; p.n_slots = s.train ? s.n_slots : 1; p.C = 256;
         p.out_slot_major = (slot_major && s.train) ? 1 : 0;
         p.pooled = pooled; p.arg = rows_too ? arg : nullptr; p.zext = rows_too ? zext : nullptr;
         return pool_finalize(p, st);

@@ -89,6 +89,19 @@ __device__ __forceinline__ void split3_bf16(const f32x4 &v, bf16x4 &p1, bf16x4 &
 
 constexpr int PW_NW = 4;   // waves per workgroup
 
+// Development probe (tools/x3_stamps.py; built only with -DAMPNET_PW_STAMPS): wave 0 of workgroup 0 of a split kernel records
+// (label, s_memtime) pairs into a device buffer -- where a wave's time goes, by phase.
+#ifdef AMPNET_PW_STAMPS
+__device__ unsigned long long g_pw_stamps[4096];
+#define PW_STAMP(id)                                                                                        \
+    do {                                                                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_n < 4000)                                          \
+            g_pw_stamps[1 + stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); \
+    } while (0)
+#else
+#define PW_STAMP(id) do { } while (0)
+#endif
+
 // 1 / x for x >= 1 to ~1e-16 relative: hardware estimate + two Newton steps (x0 (2 - d x0))
 __device__ __forceinline__ double rcp_f64(double d)
 {
@@ -353,7 +366,35 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         sgn[t] = (POOL && a.pool_gamma && col < a.cout && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
     }
   const int it_end = wg_stats ? slot_items : n_rb, it_step = wg_stats ? slot_lanes : n_lanes;
-  for (int it = wg_stats ? sl.j : lane_id; it < it_end; it += it_step) {
+  f32x4 xa[4][2];                     // split kernels: the A operand of four k steps (below); in flight ACROSS blocks of rows
+  bool xa_primed = false;
+  f32x2 s_sum2[NT], s_sq2[NT];
+  float s_ext[NT], s_z0[NT], bias_v[NT], init_v[NT];
+  int s_arg[NT];
+  int s_cnt = 0;
+  // Split kernels: a block of rows (a.chunk_rows of them, 128 from the host) belongs to ONE WAVE, which walks its tiles in row order:
+  // the eight waves of the workgroup take blocks v, v + 8 L, ... (v = 8 j + wave) and never meet inside the loop -- no barrier per
+  // block and no cross-wave merge of the pooled extremes (a wave writes its block's extremes itself); with a block shared by the
+  // eight waves those two took a third of the kernel (in-kernel stamps, tools/x3_stamps.py).  The prologue constants of the
+  // workgroup's one slot are staged before the loop.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int it_first = X3 ? (wg_stats ? sl.j : lane_id) * PW_NW + wave_u : (wg_stats ? sl.j : lane_id);
+  const int it_stride = X3 ? it_step * PW_NW : it_step;
+  if (X3) {
+      const int slot0 = wg_stats ? my_slot : 0;                   // eval mode has one slot
+      if (PRO && slot0 != staged_slot) {
+          for (int e = tid; e < CIN; e += PW_NW * 64) {
+              sPro[e] = a.pro_scale[(size_t)slot0 * CIN + e];
+              sPro[CIN + e] = a.pro_shift[(size_t)slot0 * CIN + e];
+          }
+          staged_slot = slot0;
+      }
+      __syncthreads();                                            // weights and constants are staged
+  }
+  // the sign that turns the tracked extreme of z' = sgn(gamma) z back into z, for the column this thread merges (one load, not one per block)
+  const float sg_own = (POOL && a.pool_gamma && cb0 + tid < a.cout && tid < CB && a.pool_gamma[cb0 + tid] < 0.f) ? -1.0f : 1.0f;
+  [[maybe_unused]] int stamp_n = 0;
+  for (int it = it_first; it < it_end; it += it_stride) {
     const int q = wg_stats ? my_slot + (it / a.chunks) * a.n_slots : it / a.chunks;
     const int chunk = it % a.chunks;
     const int w_begin = a.uniform_rows > 0 ? q * a.uniform_rows : a.win_off[q];
@@ -365,8 +406,8 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     const int pidx = pidx_of(q, a.n_slots, a.Q, a.perwin_slot_major);
 
     // everything the previous block of rows read from LDS (prologue constants, per-window weights, reduction scratch) is done
-    __syncthreads();
-    const bool restage = perwin_w || (PRO && slot != staged_slot);
+    if (!X3) __syncthreads();
+    const bool restage = !X3 && (perwin_w || (PRO && slot != staged_slot));
     if (restage) {
         if (perwin_w) stage_weights(pidx);
         if (PRO) {
@@ -388,23 +429,26 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     // VALU instructions do not overlap with fp32 MFMAs on this part -- tools/mfma_probe.hip -- so every epilogue instruction is
     // time taken from the matrix pipe).  z0 is only known after the wave's first tile of the block of rows: that tile starts at
     // bias and has z0 subtracted once it is known.
-    f32x2 s_sum2[NT], s_sq2[NT];
-    float s_ext[NT], s_z0[NT], bias_v[NT], init_v[NT];
-    int s_arg[NT];
-    int s_cnt = 0;
+    // Split kernels: the statistics run over ALL blocks of rows the workgroup walks (one shift z0 per wave -- its first row ever -- and
+    // one cross-wave merge at the end) instead of a merge per block: per block that merge (eight Chan steps in double per column by 128 of
+    // the 512 threads, between two barriers) took 39 % of the kernel (in-kernel stamps, tools/x3_stamps.py).  Per block only the pooled
+    // layers still combine their extremes across the waves.
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = cb0 + 32 * t + r;
-        s_z0[t] = 0.f;
-        s_sum2[t] = f32x2{0.f, 0.f};
-        s_sq2[t] = f32x2{0.f, 0.f};
+        if (!X3 || it == it_first) {
+            s_z0[t] = 0.f;
+            s_sum2[t] = f32x2{0.f, 0.f};
+            s_sq2[t] = f32x2{0.f, 0.f};
+            bias_v[t] = (!X3 && a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
+            // T-Net fc_3: the k x k output has the identity added (pointnetAtt.py:42-46): +1 on the columns i * (k + 1) of the k * k
+            if (!X3 && a.identity_k > 0 && col < a.cout && col % (a.identity_k + 1) == 0) bias_v[t] += 1.0f;
+            init_v[t] = bias_v[t];
+        }
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
-        bias_v[t] = (a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
-        // T-Net fc_3: the k x k output has the identity added (pointnetAtt.py:42-46): +1 on the columns i * (k + 1) of the k * k
-        if (a.identity_k > 0 && col < a.cout && col % (a.identity_k + 1) == 0) bias_v[t] += 1.0f;
-        init_v[t] = bias_v[t];
     }
+    if (!X3 || it == it_first) s_cnt = 0;
 
     // The epilogue of one finished 32-row tile (accumulators `acc`, rows row0 .. row0 + valid - 1).  first: the wave's first tile of this block
     // of rows (its row 0 becomes the shift z0 of the statistics); fresh: the accumulators started at the bias (z0 was not known yet).
@@ -498,33 +542,52 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         // with one 32-k block ahead (two steps) the waves spent 30 % of their time in s_waitcnt vmcnt (rocprofv3 SQ_WAIT_INST_ANY).
         static_assert(RT == 1 && (2 * NBLK) % 4 == 0, "step parity addresses the four A buffers");
         constexpr int NSTEP = 2 * NBLK, AHEAD = 3;
-        f32x4 xa[4][2];
-        auto load_step = [&](f32x4 (&dst)[2], int st_, int step_) {
+        auto load_step = [&](f32x4 (&dst)[2], int rb_, int re_, int st_, int step_) {
             // rows past the block's end re-read its last row: their products are never used
-            const int row = min(row_begin + st_ * 32 + r, row_end - 1);
+            const int row = min(rb_ + st_ * 32 + r, re_ - 1);
             const float *ap = a.A + (size_t)row * a.lda + 16 * step_ + 8 * h;
             dst[0] = *reinterpret_cast<const f32x4 *>(ap);
             dst[1] = *reinterpret_cast<const f32x4 *>(ap + 4);
         };
-        int st0 = wave;
-        if (st0 < nst) {
-#pragma unroll
-            for (int p = 0; p < AHEAD; ++p) load_step(xa[p], st0, p);
+        // the wave's first tile of the NEXT block of rows this workgroup walks: its first steps are requested under the last tile of this
+        // block, so the pipeline does not drain at the block boundary (reduction + barriers run over loads in flight)
+        int rb_n = row_begin, re_n = row_end;
+        bool next_ok = false;
+        if (it + it_stride < it_end) {
+            const int it_n = it + it_stride;
+            const int q_n = wg_stats ? my_slot + (it_n / a.chunks) * a.n_slots : it_n / a.chunks;
+            const int wb_n = a.uniform_rows > 0 ? q_n * a.uniform_rows : a.win_off[q_n];
+            const int we_n = a.uniform_rows > 0 ? wb_n + a.uniform_rows : a.win_off[q_n + 1];
+            const int b_n = wb_n + (it_n % a.chunks) * a.chunk_rows, e_n = min(we_n, b_n + a.chunk_rows);
+            if (e_n > b_n) {
+                next_ok = true;
+                rb_n = b_n;
+                re_n = e_n;
+            }
         }
-        for (; st0 < nst; st0 += PW_NW) {
-            const bool fresh0 = st0 == wave;
-            const bool more = st0 + PW_NW < nst;
+        PW_STAMP(1);                                         // block of rows begins (after the barrier)
+        int st0 = 0;
+        if (st0 < nst && !xa_primed) {
+#pragma unroll
+            for (int p = 0; p < AHEAD; ++p) load_step(xa[p], row_begin, row_end, st0, p);
+        }
+        for (; st0 < nst; ++st0) {
+            const bool fresh0 = s_cnt == 0;                  // the wave's first tile ever: its row 0 is the shift of the statistics
+            const bool more = st0 + 1 < nst;
+            // where the tail of this tile prefetches: the block's next tile, the first tile of the wave's next block, or (nothing left) itself
+            const int p_rb = more ? row_begin : rb_n, p_re = more ? row_end : re_n;
+            const int p_st = more ? st0 + 1 : (next_ok ? 0 : st0);
             f32x16 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = init_v[t];
+            PW_STAMP(2);                                     // tile begins
 #pragma unroll
             for (int sp = 0; sp < NSTEP; ++sp) {
-                // request step sp + AHEAD (of this tile, or of the wave's next one)
-                // (unconditional: behind a branch the wait counts below turn conservative, vmcnt(0) at the tile's end; the last tile re-reads itself)
-                if (sp + AHEAD < NSTEP) load_step(xa[(sp + AHEAD) & 3], st0, sp + AHEAD);
-                else load_step(xa[(sp + AHEAD) & 3], more ? st0 + PW_NW : st0, sp + AHEAD - NSTEP);
+                // request step sp + AHEAD (unconditional: behind a branch the wait counts below turn conservative, vmcnt(0) at the tile's end)
+                if (sp + AHEAD < NSTEP) load_step(xa[(sp + AHEAD) & 3], row_begin, row_end, st0, sp + AHEAD);
+                else load_step(xa[(sp + AHEAD) & 3], p_rb, p_re, p_st, sp + AHEAD - NSTEP);
                 __builtin_amdgcn_sched_barrier(0);       // the prefetch stays HERE (in the unrolled body the scheduler sinks loads to their use)
                 const int k0 = 16 * sp + 8 * h;
                 f32x4 lo = xa[sp & 3][0], hi = xa[sp & 3][1];
@@ -558,9 +621,12 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
                 }
                 __builtin_amdgcn_sched_barrier(0);   // steps do not mix: the unrolled body would otherwise hoist reads for several steps and spill
             }
+            PW_STAMP(3);                                     // k loop issued
             const int row0 = row_begin + st0 * 32;
             finish_tile(acc, row0, min(32, row_end - row0), fresh0, fresh0);
+            PW_STAMP(4);                                     // epilogue done
         }
+        xa_primed = nst > 0 && next_ok;
     } else {
     const int ntiles = (nrows + 31) / 32;
     // A fragments: blocks of 4 j (= 32 k = one 128-byte line per row), the next block prefetched in registers
@@ -781,7 +847,28 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     }
     }
 
-    if (!do_stats && !POOL) continue;
+    const bool blk_stats = !X3 && do_stats;             // split kernels: statistics are merged once, after the last block
+    if (!blk_stats && !POOL) continue;
+    if constexpr (X3 && POOL) {
+        // the block was this wave's alone: combine the two half-waves and write its extremes (empty block: -inf / -1, as pool_finalize expects)
+        const size_t o0 = (size_t)(q * a.chunks + chunk) * a.cout + cb0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float o_ext = __shfl_xor(s_ext[t], 32);
+            const int o_arg = __shfl_xor(s_arg[t], 32);
+            float f_ext = s_ext[t];
+            int f_arg = s_arg[t];
+            if (o_ext > f_ext || (o_ext == f_ext && (unsigned)o_arg < (unsigned)f_arg)) {
+                f_ext = o_ext;
+                f_arg = o_arg;
+            }
+            if (h == 0) {
+                a.part_max[o0 + 32 * t + r] = (f_ext + s_z0[t]) * sgn[t];        // back from d = z' - z0 to z
+                if (ARG) a.part_amax[o0 + 32 * t + r] = f_arg;
+            }
+        }
+        continue;
+    }
 
     // ---- combine the two half-waves, then the waves ----
     float *red_f = sRed;                                           // [PW_NW][CB][4]: S1, S2, ext, z0
@@ -809,7 +896,9 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         }
     }
     if (lane == 0) red_n[wave] = s_cnt;
+    PW_STAMP(6);                                             // partials written
     __syncthreads();
+    PW_STAMP(7);                                             // all waves arrived
     for (int c = tid; c < CB; c += PW_NW * 64) {
         const int col = cb0 + c;
         if (col >= a.cout) continue;
@@ -819,7 +908,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
 #pragma unroll
         for (int w = 0; w < PW_NW; ++w) {
             const double nw = (double)red_n[w];
-            if (do_stats && nw > 0.0) {
+            if (blk_stats && nw > 0.0) {
                 // reciprocals of the (small integer) row counts by v_rcp_f64 + two Newton steps instead of four IEEE divisions per
                 // wave: this merge sits between two barriers, i.e. on every wave's critical path (28 % of a bf16 block of rows)
                 const double s1 = red_f[(w * CB + c) * 4 + 0], s2 = red_f[(w * CB + c) * 4 + 1];
@@ -840,8 +929,8 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
             }
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
-        const float sg = (POOL && a.pool_gamma && a.pool_gamma[col] < 0.f) ? -1.0f : 1.0f;
-        if (do_stats && wg_stats) {
+        const float sg = sg_own;
+        if (blk_stats && wg_stats) {
             // merge this block of rows into the workgroup's running partial (the same thread owns column c in every block)
             if (run_n == 0) {
                 sRun[2 * c] = mean;
@@ -852,7 +941,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
                 sRun[2 * c] = rmean + delta * wgt;
                 sRun[2 * c + 1] += (m2 < 0.0 ? 0.0 : m2) + delta * delta * rn * wgt;
             }
-        } else if (do_stats) {
+        } else if (blk_stats) {
             a.part_sum[o] = sg * (float)mean;       // chunk mean (of z, not of the signed z')
             a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
@@ -862,8 +951,60 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         }
     }
     run_n += nrows;
+    PW_STAMP(5);                                             // block's reduction done
   }   // blocks of rows
+#ifdef AMPNET_PW_STAMPS
+    if (X3 && blockIdx.x == 0 && threadIdx.x == 0) g_pw_stamps[0] = (unsigned long long)stamp_n;
+#endif
     if (!(wg_stats && do_stats)) return;
+    if constexpr (X3) {
+        // the one cross-wave merge of the split kernels: per wave (rows, S1, S2, z0) over every block it walked -> Chan, fixed wave order
+        float *red_f = sRed;
+        int *red_n = reinterpret_cast<int *>(sRed + PW_NW * CB * 4) + PW_NW * CB;
+        __syncthreads();                                        // the last block's pool merge has read the scratch
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float m_sum = s_sum2[t][0] + s_sum2[t][1], m_sq = s_sq2[t][0] + s_sq2[t][1];
+            const float o_sum = __shfl_xor(m_sum, 32), o_sq = __shfl_xor(m_sq, 32);
+            if (h == 0) {
+                const int c = 32 * t + r;
+                red_f[(wave * CB + c) * 4 + 0] = m_sum + o_sum;
+                red_f[(wave * CB + c) * 4 + 1] = m_sq + o_sq;
+                red_f[(wave * CB + c) * 4 + 3] = s_z0[t];
+            }
+        }
+        if (lane == 0) red_n[wave] = s_cnt;
+        __syncthreads();
+        if (tid < CB) {
+            const int c = tid;
+            double n = 0.0, mean = 0.0, m2 = 0.0;
+            int rows = 0;
+#pragma unroll
+            for (int w = 0; w < PW_NW; ++w) {
+                const double nw = (double)red_n[w];
+                rows += red_n[w];
+                if (nw > 0.0) {
+                    const double s1 = red_f[(w * CB + c) * 4 + 0], s2 = red_f[(w * CB + c) * 4 + 1];
+                    const double nn = n + nw;
+                    const double inv_nw = rcp_f64(nw), inv_nn = rcp_f64(nn);
+                    const double mw = (double)red_f[(w * CB + c) * 4 + 3] + s1 * inv_nw;
+                    const double m2w = s2 - s1 * s1 * inv_nw;
+                    const double delta = mw - mean, wgt = nw * inv_nn;
+                    mean += delta * wgt;
+                    m2 += m2w + delta * delta * n * wgt;
+                    n = nn;
+                }
+            }
+            sRun[2 * c] = mean;
+            sRun[2 * c + 1] = m2 < 0.0 ? 0.0 : m2;
+            run_n = rows;
+        } else {
+            int rows = 0;
+#pragma unroll
+            for (int w = 0; w < PW_NW; ++w) rows += red_n[w];
+            run_n = rows;
+        }
+    }
     // ---- the workgroup's partial (thread c wrote sRun[c] itself: no barrier needed), or the finished BatchNorm constants ----
     for (int c = tid; c < CB; c += PW_NW * 64) {
         const int col = cb0 + c;
@@ -944,7 +1085,8 @@ static int launch_pw_x(const PwGemm &a, hipStream_t st)
 {
     if (precision_is_f32()) {
         if constexpr (pw_x3_built<CIN, NT, PRO, POOL>) {
-            if (precision_split() && !a.w_win_stride && a.uniform_rows == 0 && a.cout % (32 * NT) == 0 && (POOL || a.Z)) {       // the real point layers (not the T-Net FC rows)
+            if (precision_split() && !a.w_win_stride && a.uniform_rows == 0 && a.cout % (32 * NT) == 0 && (POOL || a.Z) && !a.bias && !a.identity_k &&
+                (!a.part_sum || a.part_rows)) {       // the real point layers (not the T-Net FC rows)
                 if constexpr (POOL) {
                     if (!a.part_amax) return launch_pw_y<CIN, NT, PRO, POOL, true, false, false, false, false, true, PW_X3_NW>(a, st);
                 }
@@ -1049,3 +1191,12 @@ int pw_gemm(const PwGemm &a, hipStream_t st)
 }
 
 }  // namespace ampnet
+
+#ifdef AMPNET_PW_STAMPS
+extern "C" int ampnet_debug_pw_stamps(unsigned long long *host_out, int max_entries)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t n = (size_t)(max_entries < 4096 ? max_entries : 4096);
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ampnet::g_pw_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
