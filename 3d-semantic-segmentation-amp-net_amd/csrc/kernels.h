@@ -345,6 +345,8 @@ bool pw_bwd_supported(int cx, int cy);
 int pw_bwd_item_rows();
 int pw_bwd_fused(const PwBwd &a, hipStream_t st);
 int pw_bwd_fused_bf16(const PwBwd &a, hipStream_t st);     // the same pass with bf16 MFMA operands (pw_bwd_bf16.hip); pw_bwd_fused dispatches
+bool pw_bwd_x3_supported(const PwBwd &a);                  // precision mode 4: the shapes pw_bwd_x3.hip is built for (128 x 128, Gram or dense)
+int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st);       // the same pass with three-term bf16 split operands (fp32 results); pw_bwd_fused dispatches
 
 // dst[i] (= or +=) sum_q part[q * stride + i], i < n, fixed order; dst row-remap for strided destinations:
 // element i = (r, c) with c < cols -> dst[r * ld_dst + c]

@@ -631,6 +631,7 @@ int pw_bwd_fused(const PwBwd &a_in, hipStream_t st)
                                      a.fin_P3 && a.fin_slot_ab && !a.g.act && a.fin_part_a != a.part_a),
                    "pw_bwd_fused: in-kernel BatchNorm-backward constants need the partials of the producer (not this launch's), the layer's statistics and outputs");
     AMPNET_REQUIRE(!a.fin_part_a || !bwd_operands_bf16(), "pw_bwd_fused: in-kernel BatchNorm-backward constants are built for the fp32 kernel");
+    if (precision_split() && pw_bwd_x3_supported(a)) return pw_bwd_fused_x3(a, st);     // fp32 results from the bf16 pipe (pw_bwd_x3.hip)
     if (bwd_operands_bf16()) return pw_bwd_fused_bf16(a, st);
     AMPNET_REQUIRE(!a.g.z_bf16 && !a.prev.z_bf16, "pw_bwd_fused: bf16 activation tensors need a bf16 precision mode");      // bf16 MFMA operands (pw_bwd_bf16.hip)
     if (a.g.C == 128 && a.prev.C == 128) return launch_fused<128, 128, 32>(a, st);

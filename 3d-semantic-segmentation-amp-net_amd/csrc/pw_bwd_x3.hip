@@ -1,0 +1,518 @@
+// pw_bwd_x3.hip -- the fused backward of pw_bwd_fused.hip for the MFMA-bound 128 x 128 shapes in precision mode
+// AMPNET_PRECISION_F32_SPLIT: fp32 results from the bf16 matrix pipe.
+//
+// Same launch interface (PwBwd), work split, roles and fp32 epilogue as the fp32 kernel; every operand of the two products is split into
+// three bf16 terms x = x1 + x2 + x3 (round to nearest each time: the sum is the fp32 value exactly) and a product is the six partial
+// products x1 y1, x1 y2, x2 y1, x1 y3, x2 y2, x3 y1 on v_mfma_f32_32x32x16_bf16 (each exact in fp32, the dropped terms are below
+// 2^-23 |x y|), accumulated in fp32: 6 / 16 of the fp32 MFMA time.
+//     sG[i][row][cx] = i-th bf16 term of g = dy * P1 + z * P2 + P3 (or of a = relu(z * P2 + P3) for the Gram form), split ONCE while staged
+//     sY[i][row][cy] = i-th term of a_prev = relu(bn(z_prev))  (dense form only; the Gram form's y IS g)
+//     sZ[row][cy]    = the ACTIVATED input a_prev in fp32: ReLU mask (a > 0) and zhat = (a - beta) / gamma for the data gradient's epilogue
+// W waves:  dW[cx][cy] += sum_rows g[row][cx] * y[row][cy], k = rows: operands are columns of the row-major tiles (ds_read_b64_tr_b16)
+// D waves:  dy_prev[row][cy] = sum_cx g[row][cx] * W[cx][cy], k = cx; a D wave owns ONE 32-column block for the whole launch, so its 8 x 3
+//           weight fragments (per-slot matrix of the pooled layers, shared weights otherwise) live in 96 VGPRs -- no weight image in LDS,
+//           which three images of two staged tiles already fill.
+// Built for: Gram form 128 x 128 (the three pooled layers' backward) and the dense 128 x 128 layer (conv_5), activated input, no addend.
+#include <type_traits>
+#include "kernels.h"
+
+namespace ampnet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int X3B_THREADS = 512;
+constexpr int X3B_ITEM_ROWS = 256;      // must equal pw_bwd_item_rows() (the host sizes per-window shares with it)
+
+namespace {
+
+// the three-term split on pairs (pw_gemm.hip has the same helpers; see there for why the conversion is an instruction)
+__device__ __forceinline__ uint32_t cvt_pk(const f32x2 &v)
+{
+    uint32_t p;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(v[0]), "v"(v[1]));
+    return p;
+}
+__device__ __forceinline__ f32x2 widen_pk(uint32_t p) { return f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)}; }
+__device__ __forceinline__ void split_pair(const f32x2 &x, uint32_t &p1, uint32_t &p2, uint32_t &p3)
+{
+    p1 = cvt_pk(x);
+    const f32x2 r = x - widen_pk(p1);
+    p2 = cvt_pk(r);
+    p3 = cvt_pk(r - widen_pk(p2));
+}
+__device__ __forceinline__ void split4(const f32x4 &v, bf16x4 &p1, bf16x4 &p2, bf16x4 &p3)
+{
+    uint32_t q1[2], q2[2], q3[2];
+    split_pair(f32x2{v[0], v[1]}, q1[0], q2[0], q3[0]);
+    split_pair(f32x2{v[2], v[3]}, q1[1], q2[1], q3[1]);
+    p1 = __builtin_bit_cast(bf16x4, u32x2{q1[0], q1[1]});
+    p2 = __builtin_bit_cast(bf16x4, u32x2{q2[0], q2[1]});
+    p3 = __builtin_bit_cast(bf16x4, u32x2{q3[0], q3[1]});
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &p1, bf16x8 &p2, bf16x8 &p3)
+{
+    uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair(f32x2{v[2 * i], v[2 * i + 1]}, q1[i], q2[i], q3[i]);
+    p1 = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+    p2 = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+    p3 = __builtin_bit_cast(bf16x8, u32x4{q3[0], q3[1], q3[2], q3[3]});
+}
+
+// MFMA operand whose k runs over the ROWS of a row-major bf16 tile: rows row0 .. row0 + 15, channel col0 + (lane & 31) (pw_bwd_bf16.hip)
+__device__ __forceinline__ bf16x8 tr_operand(const __bf16 *tile, int ld, int row0, int col0, int lane)
+{
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16 *src = tile + (row0 + 8 * (g4 >> 1) + q) * ld + col0 + 16 * (g4 & 1) + 4 * p;
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * ld));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// acc += x * y from the three terms of each: six exact partial products, the small ones first
+__device__ __forceinline__ void mfma6(f32x16 &acc, const bf16x8 (&x)[3], const bf16x8 (&y)[3])
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], acc, 0, 0, 0);
+}
+
+}  // namespace
+
+template <bool GRAM>
+__global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
+{
+    constexpr int CX = 128, CY = 128, ROWS = 32;
+    constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 elements per row of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
+    constexpr int LDZ = CY + 4;                     // fp32 row of the activated-input tile
+    constexpr int TYN = CY / 32;
+    constexpr int TXW = 2, TYW = 2;                 // W role: 2 x 2 tiles per wave
+    constexpr int STAGE = X3B_THREADS;
+    constexpr int QX = CX / 4, SX = STAGE / QX;     // 32 channel quads, 16 row groups
+    constexpr int NIX = ROWS / SX;                  // 2 quads per thread and tensor
+    constexpr int IMG = ROWS * LDG;                 // elements of one image of one buffer
+    static_assert(CX == CY && LDG == LDY && (ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16 *sG = reinterpret_cast<__bf16 *>(smem_raw);                                   // [2 buffers][3 terms][ROWS][LDG]
+    __bf16 *sY = sG + 2 * 3 * IMG;                                                       // the same for a_prev (dense form)
+    float *sZ = reinterpret_cast<float *>(sY + (GRAM ? 0 : 2 * 3 * IMG));                // [2][ROWS][LDZ] activated input, fp32
+    float *red = reinterpret_cast<float *>(smem_raw);                                    // reductions alias the tiles (before / after the loop)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
+
+    // ---- work split: items = (window of this slot, chunk of X3B_ITEM_ROWS rows), contiguous share per workgroup ----
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    const int cpw = (a.max_rows + X3B_ITEM_ROWS - 1) / X3B_ITEM_ROWS;
+    const int n_items = per_slot * cpw;
+    const int ipb = a.items_per_block > 0 ? a.items_per_block : (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
+    const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
+
+    const int cqx = tid % QX, rsx = tid / QX;
+    f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
+    if (!GRAM && a.fin_part_a) {
+        // the BatchNorm-backward constants of this layer from the partial sums its producer left (pw_bwd_fused.hip: fin_*)
+        double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+        const int per_slot_parts = (a.fin_parts - slot + a.n_slots - 1) / a.n_slots;
+        for (int k0 = rsx; k0 < per_slot_parts; k0 += SX * 8) {
+            f32x4 va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + SX * u;
+                const size_t o = (size_t)(slot + (k < per_slot_parts ? k : 0) * a.n_slots) * CX + 4 * cqx;
+                va[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_a + o);
+                vb[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_b + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + SX * u < per_slot_parts) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sa[c] += (double)va[u][c];
+                        sb[c] += (double)vb[u][c];
+                    }
+                }
+            }
+        }
+        double *redd = reinterpret_cast<double *>(smem_raw);          // [SX][CX][2]: the staging buffers are not in use yet
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            redd[((size_t)rsx * CX + 4 * cqx + c) * 2 + 0] = sa[c];
+            redd[((size_t)rsx * CX + 4 * cqx + c) * 2 + 1] = sb[c];
+        }
+        __syncthreads();
+        const double n = (double)a.fin_rows;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * cqx + c;
+            double A = 0.0, Bs = 0.0;
+            for (int gq = 0; gq < SX; ++gq) {
+                A += redd[((size_t)gq * CX + ch) * 2 + 0];
+                Bs += redd[((size_t)gq * CX + ch) * 2 + 1];
+            }
+            const size_t o = (size_t)slot * CX + ch;
+            const double invstd = a.fin_invstd[o], mean = a.fin_mean[o];
+            const double s = (double)a.fin_gamma[ch] * invstd;
+            const double q2 = -s * invstd * Bs / n;
+            p1[c] = (float)s;
+            p2[c] = (float)q2;
+            p3[c] = (float)(-s * A / n - q2 * mean);
+            if (jb == 0 && rsx == 0) {                       // one writer per slot: the arrays other kernels read
+                a.fin_slot_ab[o * 2 + 0] = (float)A;
+                a.fin_slot_ab[o * 2 + 1] = (float)Bs;
+            }
+        }
+        if (jb == 0 && rsx == 0) {
+            *reinterpret_cast<f32x4 *>(a.fin_P1 + (size_t)slot * CX + 4 * cqx) = p1;
+            *reinterpret_cast<f32x4 *>(a.fin_P2 + (size_t)slot * CX + 4 * cqx) = p2;
+            *reinterpret_cast<f32x4 *>(a.fin_P3 + (size_t)slot * CX + 4 * cqx) = p3;
+        }
+        __syncthreads();                                             // the scratch becomes the first tile
+    } else {
+        if (!GRAM) p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
+        p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
+        p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
+    }
+    f32x4 ys = {1.f, 1.f, 1.f, 1.f}, yt = {0.f, 0.f, 0.f, 0.f};             // the input activation's affine, staging view (dense form)
+    if (!GRAM) {
+        ys = *reinterpret_cast<const f32x4 *>(a.prev.s + (size_t)slot * CY + 4 * cqx);
+        yt = *reinterpret_cast<const f32x4 *>(a.prev.t + (size_t)slot * CY + 4 * cqx);
+    }
+
+    struct Pos {
+        int item, row0, row_end;
+    };
+    auto open_item = [&](int item, Pos &p) -> bool {
+        for (; item < item_end; ++item) {
+            const int q = (item / cpw) * a.n_slots + slot, ch = item % cpw;
+            const int rb = a.win_off[q] + ch * X3B_ITEM_ROWS;
+            const int re = min(a.win_off[q + 1], rb + X3B_ITEM_ROWS);
+            if (rb < re) {
+                p.item = item;
+                p.row0 = rb;
+                p.row_end = re;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto advance = [&](Pos &p) -> bool {
+        if (p.row0 + ROWS < p.row_end) {
+            p.row0 += ROWS;
+            return true;
+        }
+        return open_item(p.item + 1, p);
+    };
+
+    // two register sets of loads in flight (blocks n + 1 and n + 2), issued unconditionally (pw_bwd_bf16.hip explains both)
+    struct Regs {
+        f32x4 dy[GRAM ? 1 : NIX];
+        f32x4 xz[NIX];
+        f32x4 yz[GRAM ? 1 : NIX];
+    };
+    auto load_regs = [&](const Pos &p, Regs &R) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int row = p.row0 + rsx + SX * i;
+            const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            if (!GRAM) R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
+            R.xz[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+            if (!GRAM) R.yz[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqx);
+        }
+    };
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    const bool want_db = a.dbpart != nullptr;
+    auto write_lds = [&](int buf_, const Pos &p, const Regs &R) {
+        int bsel = buf_;
+        asm volatile("" : "+s"(bsel));               // (see step(): keeps the addresses of the two buffers from being hoisted apart)
+        __bf16 *g = sG + bsel * 3 * IMG;
+        __bf16 *y = sY + bsel * 3 * IMG;
+        float *z = sZ + bsel * ROWS * LDZ;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int lrow = rsx + SX * i, row = p.row0 + lrow;
+            const bool live_row = row < p.row_end;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (live_row) {
+                if (GRAM) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaxf(fmaf(R.xz[i][c], p2[c], p3[c]), 0.f);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[c] = fmaf(R.dy[i][c], p1[c], fmaf(R.xz[i][c], p2[c], p3[c]));
+                }
+                if (want_db) dbacc += xv;
+            }
+            bf16x4 t1, t2, t3;
+            split4(xv, t1, t2, t3);
+            *reinterpret_cast<bf16x4 *>(g + lrow * LDG + 4 * cqx) = t1;
+            *reinterpret_cast<bf16x4 *>(g + IMG + lrow * LDG + 4 * cqx) = t2;
+            *reinterpret_cast<bf16x4 *>(g + 2 * IMG + lrow * LDG + 4 * cqx) = t3;
+            if (GRAM) {
+                *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqx) = xv;           // the activated input IS g here
+            } else {
+                f32x4 yv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yv[c] = fmaxf(fmaf(R.yz[i][c], ys[c], yt[c]), 0.f);
+                *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqx) = yv;           // (finite filler on rows past the end: masked in the epilogue)
+                if (!live_row) yv = f32x4{0.f, 0.f, 0.f, 0.f};                       // rows past the block's end contribute nothing to dW
+                split4(yv, t1, t2, t3);
+                *reinterpret_cast<bf16x4 *>(y + lrow * LDY + 4 * cqx) = t1;
+                *reinterpret_cast<bf16x4 *>(y + IMG + lrow * LDY + 4 * cqx) = t2;
+                *reinterpret_cast<bf16x4 *>(y + 2 * IMG + lrow * LDY + 4 * cqx) = t3;
+            }
+        }
+    };
+
+    // ---- role state ----
+    const bool w_role = wave < 4;
+    const int ww = wave & 3;
+    const int tx0 = (ww / 2) * TXW, ty0 = (ww % 2) * TYW;
+    f32x16 acc_w[TXW][TYW];
+#pragma unroll
+    for (int i = 0; i < TXW; ++i)
+#pragma unroll
+        for (int j = 0; j < TYW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_w[i][j][e] = 0.f;
+    // D role: tile (rows 0 .. 31, columns 32 ww ..), lane = output column; its weight column block as three bf16 terms in registers
+    const int dcol = 32 * ww + r;
+    bf16x8 wf[CX / 16][3];
+    if (!w_role) {
+        const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+#pragma unroll
+        for (int s2 = 0; s2 < CX / 16; ++s2) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol];
+            split8(v, wf[s2][0], wf[s2][1], wf[s2][2]);
+        }
+    }
+    const float c_b = a.bias_slot ? a.bias_slot[(size_t)slot * CY + dcol] : 0.f;
+    const float c_s = a.prev.s[(size_t)slot * CY + dcol];
+    const float c_t = a.prev.t[(size_t)slot * CY + dcol];
+    const float c_m = a.prev_mean ? a.prev_mean[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_i = a.prev_invstd ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_beta = fmaf(c_m, c_s, c_t);                      // t = beta - mean s
+    const float c_invg = c_s != 0.f ? c_i / c_s : 0.f;             // gamma = s / invstd; gamma = 0: P2 = 0, any finite zhat will do
+    const bool do_part = a.part_a != nullptr;
+    float s_a = 0.f, s_b = 0.f;
+
+    // Positions of block n (in LDS) and of the blocks whose loads are in flight.  Gram form (8 registers per block and thread): TWO register
+    // sets, blocks n + 1 and n + 2 in flight (one set caps the bytes in flight per CU below what 0.3 ms per launch needs).  Dense form
+    // (dy, z and z_prev: 24 registers per block and thread, next to the D role's 96 weight registers): ONE set -- a block of rows is 96 MFMAs
+    // per SIMD here, 3072 cycles, which covers a trip to HBM, and the second set spilled into the loop.  A tail position that does not exist
+    // repeats the last real one: the loads are issued unconditionally (a conditional load makes every wait a vmcnt(0)), their data is not written.
+    constexpr int NSETS = GRAM ? 2 : 1;
+    Pos cur, nxt, nx2;
+    bool live = open_item(item_begin, cur);
+    bool more1 = false, more2 = false;
+    nxt = cur;
+    if (live) more1 = advance(nxt);
+    if (!more1) nxt = cur;
+    nx2 = nxt;
+    if (more1) more2 = advance(nx2);
+    if (!more2) nx2 = nxt;
+    Regs S0, S1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every constant has landed before the loop (see pw_bwd_fused.hip)
+    if (live) {
+        load_regs(cur, S0);
+        if (NSETS == 2) load_regs(nxt, S1);
+        write_lds(0, cur, S0);
+        load_regs(NSETS == 2 ? nx2 : nxt, S0);
+    }
+    __syncthreads();
+    int buf = 0;
+    // one block of rows: compute block n from LDS, write block n + 1 (register set A) into the other buffer, refill A.  The two roles run
+    // the loop as two separate instantiations (role_tag): every wait is then a static count of the role's own younger memory operations.
+    auto step = [&](Regs &A, auto role_tag) {
+        constexpr bool W_ROLE = decltype(role_tag)::value;
+        // the buffer index stays a run-time scalar: folded (the loop alternates two step bodies) every LDS address of both buffers is hoisted
+        // into a register of its own, ~60 of them, and they spill into the loop
+        int bsel = buf;
+        asm volatile("" : "+s"(bsel));
+        const __bf16 *g = sG + bsel * 3 * IMG;
+        const __bf16 *y = GRAM ? g : sY + bsel * 3 * IMG;
+        const float *z = sZ + bsel * ROWS * LDZ;
+        if constexpr (W_ROLE) {
+#pragma unroll
+            for (int s2 = 0; s2 < ROWS / 16; ++s2) {
+                bf16x8 xa[TXW][3], yb[TYW][3];
+#pragma unroll
+                for (int i = 0; i < TXW; ++i)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (tx0 + i), lane);
+#pragma unroll
+                for (int j = 0; j < TYW; ++j)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) yb[j][m] = tr_operand(y + m * IMG, LDG, 16 * s2, 32 * (ty0 + j), lane);
+#pragma unroll
+                for (int i = 0; i < TXW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TYW; ++j) mfma6(acc_w[i][j], xa[i], yb[j]);
+            }
+        } else {
+            const int valid = min(ROWS, cur.row_end - cur.row0);           // rows of this tile that exist
+            const int trow0 = cur.row0;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = c_b;
+            const __bf16 *ga = g + r * LDG + 8 * h;
+#pragma unroll
+            for (int s2 = 0; s2 < CX / 16; ++s2) {
+                bf16x8 av[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) av[m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG + 16 * s2);
+                mfma6(acc, av, wf[s2]);
+            }
+            float zv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+            float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
+            auto finish = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = FULL || rr < valid;
+                    float v = acc[e];
+                    v = zv[e] > 0.f ? v : 0.f;                               // ReLU mask of the layer's input: a > 0
+                    const float vs = ok ? v : 0.f;
+                    s_a += vs;
+                    s_b = fmaf(vs, (zv[e] - c_beta) * c_invg, s_b);          // zhat = (a - beta) / gamma where the mask holds
+                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                }
+            };
+            if (valid >= 32) finish(std::true_type{});
+            else finish(std::false_type{});
+        }
+        if constexpr (NSETS == 2) {
+            Pos nx3 = nx2;
+            const bool more3 = more2 && advance(nx3);
+            if (!more3) nx3 = nx2;
+            if (more1) write_lds(buf ^ 1, nxt, A);
+            load_regs(nx3, A);
+            __syncthreads();
+            buf ^= 1;
+            cur = nxt;
+            nxt = nx2;
+            nx2 = nx3;
+            live = more1;
+            more1 = more2;
+            more2 = more3;
+        } else {
+            if (more1) write_lds(buf ^ 1, nxt, A);
+            load_regs(nx2, A);                       // block n + 2 (or a repeat of the last real one)
+            __syncthreads();
+            buf ^= 1;
+            cur = nxt;
+            nxt = nx2;
+            live = more1;
+            more1 = more2;
+            more2 = more1 && advance(nx2);
+            if (!more2) nx2 = nxt;
+        }
+    };
+    if (w_role) {
+        while (live) {
+            step(NSETS == 2 ? S1 : S0, std::true_type{});
+            if (!live) break;
+            step(S0, std::true_type{});
+        }
+    } else {
+        while (live) {
+            step(NSETS == 2 ? S1 : S0, std::false_type{});
+            if (!live) break;
+            step(S0, std::false_type{});
+        }
+    }
+
+    // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
+    if (w_role) {
+        float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
+#pragma unroll
+        for (int i = 0; i < TXW; ++i)
+#pragma unroll
+            for (int j = 0; j < TYW; ++j) {
+                const int cy = 32 * (ty0 + j) + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int cx = 32 * (tx0 + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    dst[(size_t)cx * CY + cy] = acc_w[i][j][e];
+                }
+            }
+    }
+    if (a.dbpart) {
+        *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        __syncthreads();
+        if (tid < CX) {
+            float s = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < SX; ++gi) s += red[gi * CX + tid];
+            a.dbpart[(size_t)blockIdx.x * CX + tid] = s;
+        }
+        __syncthreads();
+    }
+    if (do_part) {
+        const float oa = __shfl_xor(s_a, 32), ob = __shfl_xor(s_b, 32);
+        if (!w_role && h == 0) {
+            red[dcol * 2 + 0] = s_a + oa;
+            red[dcol * 2 + 1] = s_b + ob;
+        }
+        __syncthreads();
+        if (tid < CY) {
+            a.part_a[(size_t)blockIdx.x * CY + tid] = red[tid * 2 + 0];
+            a.part_b[(size_t)blockIdx.x * CY + tid] = red[tid * 2 + 1];
+        }
+    }
+}
+
+template <bool GRAM>
+static int launch_x3(const PwBwd &a, hipStream_t st)
+{
+    constexpr size_t img = (size_t)32 * 160 * 2;
+    constexpr size_t lds = 2 * 3 * img * (GRAM ? 1 : 2) + (size_t)2 * 32 * 132 * 4;
+    static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
+    static bool attr_set = false;
+    auto kern = pw_bwd_x3_kernel<GRAM>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_x3: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    char name[64];
+    snprintf(name, sizeof(name), "pw_bwd<128,128>%s x3", GRAM ? "+gram" : "");
+    const double rows = (double)a.rows_hint;
+    ProfScope prof(name, 4.0 * rows * 128 * 128, rows * 4.0 * ((a.g.dy ? 128 : 0) + 128 + (GRAM ? 0 : 128) + 128), st);
+    hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(X3B_THREADS), lds, st, a);
+    return check_launch("pw_bwd_x3_kernel");
+}
+
+// the shapes the split backward is built for; pw_bwd_fused() asks before it dispatches here
+bool pw_bwd_x3_supported(const PwBwd &a)
+{
+    const bool gram = a.g.act != 0;
+    return a.g.C == 128 && a.prev.C == 128 && a.prev.s != nullptr && !a.add && !(a.prev.drop_p > 0.f) && !a.w_win_stride && !a.g.z_bf16 && !a.prev.z_bf16 &&
+           (gram ? a.g.z == a.prev.z : (a.g.dy != nullptr));
+}
+
+// same argument contract as pw_bwd_fused (it validates before dispatching here)
+int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st)
+{
+    static_assert(X3B_ITEM_ROWS == 256, "item size shared with pw_bwd_fused.hip");
+    AMPNET_REQUIRE(pw_bwd_x3_supported(a), "pw_bwd_x3: shape not built");
+    return a.g.act ? launch_x3<true>(a, st) : launch_x3<false>(a, st);
+}
+
+}  // namespace ampnet
