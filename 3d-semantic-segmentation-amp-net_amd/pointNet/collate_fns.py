@@ -1,4 +1,4 @@
-"""collate_seq_padd with the reference's name, output layout and random draws (pointNet/collate_fns.py:4-55):
+"""collate_seq_padd / collate_cls_padd with the reference's name, output layout and random draws (pointNet/collate_fns.py:4-55):
 every sample is brought to exactly 2048 points per cluster (torch.randint with replacement when it has fewer,
 random.sample when it has more -- the same calls in the same order, so a seeded run collates identically),
 clusters are padded to 9 (data and centroids by replicating the last cluster, targets with -1), and the centroids
@@ -44,3 +44,33 @@ def collate_seq_padd(batch):
         cents.append(_pad_last(cent, MAX_WINDOWS, "replicate"))
         names.append(name)
     return torch.stack(data, 0), torch.stack(targets, 0), names, torch.stack(cents, 0).view(-1, MAX_WINDOWS, 2)
+
+
+def collate_cls_padd(batch):
+    """The classification collate of the reference (pointNet/collate_fns.py:58-113) for the window-token classifier:
+    batch: list of (pc [n, d, w] float, target, filename, centroids [2, w] float, labels_segmen [n, w] int)
+    -> (data [B, 2048, d, 9] f32, targets [B, ...] i64, filenames, centroids [B, 9, 2] f32, labels_segmen [B, 2048, 9] i64).
+    Points are resampled to 2048 per cluster and clusters padded to 9 exactly as in collate_seq_padd (same torch / python RNG calls
+    in the same order; data and centroids replicate the last cluster, the segmentation labels are padded with -1; the centroids
+    leave through the same `.view(-1, 9, 2)` reinterpretation).  `target` is stacked as given; hand it over as a sequence ([1], an
+    array): the reference builds it with torch.LongTensor(t[1]) (:74), which for a bare int k ALLOCATES k uninitialised elements
+    instead of holding k -- a bare int is taken as the label here."""
+    data, targets, names, cents, seg = [], [], [], [], []
+    for pc, target, name, cent, labels in batch:
+        pc = torch.as_tensor(pc).float()
+        labels = torch.as_tensor(labels).long()
+        cent = torch.as_tensor(cent).float().unsqueeze(1)            # [2, 1, w]
+        n = pc.shape[0]
+        if n < N_POINTS:
+            idx = torch.randint(0, n, (N_POINTS,))
+            pc, labels = pc[idx], labels[idx]
+        elif n > N_POINTS:
+            idx = random.sample(range(n), N_POINTS)
+            pc, labels = pc[idx], labels[idx]
+        data.append(_pad_last(pc, MAX_WINDOWS, "replicate"))
+        cents.append(_pad_last(cent, MAX_WINDOWS, "replicate"))
+        seg.append(_pad_last(labels, MAX_WINDOWS, -1))
+        targets.append(torch.as_tensor(target).long())
+        names.append(name)
+    return (torch.stack(data, 0), torch.stack(targets, 0), names, torch.stack(cents, 0).view(-1, MAX_WINDOWS, 2),
+            torch.stack(seg, 0))

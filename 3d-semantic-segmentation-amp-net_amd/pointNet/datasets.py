@@ -1,5 +1,6 @@
 """Datasets of the AMP-Net path with the reference's class names, constructor arguments and return values
-(pointNet/datasets.py:295-460 LidarKmeansDataset, :463-515 LidarDataset4Test).  CPU only (DataLoader workers).
+(pointNet/datasets.py:9-142 LidarDataset, :145-292 LidarDatasetExpanded, :295-460 LidarKmeansDataset, :463-515 LidarDataset4Test,
+:518-565 LidarInferenceDataset).  CPU only (DataLoader workers).
 
 On-disk formats (unchanged): `kmeans_<name>.pt` = torch tensor [n, >=10, w] with columns x, y, HAG, class, I, R, G,
 B, NIR, NDVI, ... (data_proc/3_kmeans.py:116); test files = pickled numpy [n, >=10] rows with the same columns."""
@@ -135,3 +136,100 @@ class LidarDatasetExpanded(data.Dataset):
         pc[:, 0] = pc[:, 0] * 2 - 1
         pc[:, 1] = pc[:, 1] * 2 - 1
         return pc, labels, filename
+
+
+class LidarDataset(data.Dataset):
+    """Single-window samples of the tower / no-tower classifier (pointNet/datasets.py:9-142): a file = pickled numpy [n, >= 10] rows
+    (x, y, HAG, class, I, R, G, B, NIR, NDVI, sampling flag); the class of a SAMPLE is in its file name ('pc_' -> 0, 'tower_' -> 1).
+    __getitem__ -> (pc [n', 7] float32 ndarray = columns x, y, HAG, I, G, B, NDVI (:60), labels, filename); labels = the sample's class
+    (task 'classification') or the per-point segmentation labels from column 3 (task 'segmentation', LongTensor [n']).
+    Resampling to number_of_points uses numpy's global RNG like the reference (np.random.choice WITH replacement when there are more
+    points, np.random.randint duplicates appended when there are fewer, :78-88), so a seeded run draws the same rows."""
+    NUM_CLASSIFICATION_CLASSES = 2
+    POINT_DIMENSION = 2
+
+    def __init__(self, dataset_folder, task='classification', number_of_points=None, number_of_windows=None, files=None,
+                 fixed_num_points=True, c_sample=False, allow_pickle=None):
+        self.dataset_folder = dataset_folder
+        self.task = task
+        self.n_points = number_of_points
+        self.n_windows = number_of_windows
+        self.files = files
+        self.fixed_num_points = fixed_num_points
+        self.allow_pickle = allow_pickle
+        self.classes_mapping = {}
+        self.constrained_sampling = c_sample
+        self.paths_files = [os.path.join(self.dataset_folder, f) for f in self.files]
+        self._init_mapping()
+
+    def __len__(self):
+        return len(self.paths_files)
+
+    def _init_mapping(self):
+        for f in self.files:
+            if 'pc_' in f:
+                self.classes_mapping[f] = 0
+            elif 'tower_' in f:
+                self.classes_mapping[f] = 1
+        self.len_towers = sum(v == 1 for v in self.classes_mapping.values())
+        self.len_landscape = sum(v == 0 for v in self.classes_mapping.values())
+
+    def __getitem__(self, index):
+        filename = self.paths_files[index]
+        pc = self.prepare_data(filename, self.n_points, fixed_num_points=self.fixed_num_points,
+                               constrained_sample=self.constrained_sampling, allow_pickle=self.allow_pickle)
+        labels = self.get_labels(pc, self.classes_mapping[self.files[index]], self.task)
+        pc = pc.numpy()
+        return np.concatenate((pc[:, :3], pc[:, 4:5], pc[:, 6:8], pc[:, 9:10]), axis=1), labels, filename
+
+    @staticmethod
+    def prepare_data(point_file, number_of_points=None, fixed_num_points=True, constrained_sample=False, allow_pickle=None):
+        pc = np.asarray(load_numpy_pickle(point_file, allow_pickle)).astype(np.float32)
+        if constrained_sample:
+            pc = pc[pc[:, 10] == 1]                                     # rows flagged for sampling
+        if fixed_num_points and pc.shape[0] > number_of_points:
+            pc = pc[np.random.choice(pc.shape[0], number_of_points), :]
+        elif fixed_num_points and pc.shape[0] < number_of_points:
+            extra = np.random.randint(0, pc.shape[0], number_of_points - pc.shape[0])
+            pc = np.concatenate([pc, pc[extra, :]], axis=0)
+        return torch.from_numpy(pc)
+
+    @staticmethod
+    def get_labels(pointcloud, point_cloud_class, task='classification'):
+        """'segmentation': {0 background, 1 tower (15), 2 lines (14), 3 low / medium vegetation (3, 4), 4 high vegetation (5)} per point
+        from column 3 (:118-131); 'classification': the sample's class."""
+        if task == 'segmentation':
+            return segmentation_labels(pointcloud[:, 3])
+        if task == 'classification':
+            return point_cloud_class
+        raise ValueError(f"task {task!r}: 'classification' or 'segmentation'")        # (the reference leaves `labels` unbound here)
+
+
+class LidarInferenceDataset(data.Dataset):
+    """Raw samples for inference (pointNet/datasets.py:518-565): __getitem__ -> (pc [n', >= 10] float32 tensor with every column of
+    the file, filename); with c_sample only the rows whose flag column 10 is 1."""
+    NUM_CLASSIFICATION_CLASSES = 2
+    POINT_DIMENSION = 2
+
+    def __init__(self, dataset_folder, task='classification', files=None, c_sample=False, allow_pickle=None):
+        self.dataset_folder = dataset_folder
+        self.task = task
+        self.files = files
+        self.allow_pickle = allow_pickle
+        self.classes_mapping = {}
+        self.constrained_sampling = c_sample
+        self.paths_files = [os.path.join(self.dataset_folder, f) for f in self.files]
+
+    def __len__(self):
+        return len(self.paths_files)
+
+    def __getitem__(self, index):
+        filename = self.paths_files[index]
+        return self.prepare_data(filename, constrained_sample=self.constrained_sampling, allow_pickle=self.allow_pickle), filename
+
+    @staticmethod
+    def prepare_data(point_file, constrained_sample=False, allow_pickle=None):
+        pc = np.asarray(load_numpy_pickle(point_file, allow_pickle)).astype(np.float32)
+        if constrained_sample:
+            pc = pc[pc[:, 10] == 1]
+        return torch.from_numpy(pc)

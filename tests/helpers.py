@@ -49,3 +49,12 @@ def baseline_state(synth, table, base):
             b = 1.0 / np.sqrt(fan)
             sd[k] = synth.uniform(base + i, shp, -b, b)
     return sd
+
+
+def cls_sample_array(synth, seed, n):
+    """A classification sample file's array [n, 11]: x, y, HAG, class code, I, R, G, B, NIR, NDVI, sampling flag (seeded)."""
+    a = synth.uniform(seed, (n, 11), 0.0, 1.0).astype(np.float32)
+    codes = np.array([15, 14, 3, 4, 5, 6, 9, 1], dtype=np.float32)
+    a[:, 3] = codes[synth.randint(seed + 1, (n,), 0, len(codes))]
+    a[:, 10] = (synth.randint(seed + 2, (n,), 0, 3) > 0).astype(np.float32)
+    return a

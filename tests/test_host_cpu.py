@@ -189,3 +189,57 @@ def test_pickled_inputs_need_an_explicit_opt_in(tmp_path, monkeypatch):
     p_t = tmp_path / "c.pkl"
     torch.save([torch.ones(2, 3)], p_t)
     assert torch.equal(SL.load_tensor_list(str(p_t))[0], torch.ones(2, 3))
+
+
+def test_lidar_dataset_and_inference_dataset_match_reference(golden, synth, tmp_path):
+    """pointNet/datasets.py:9-142 (LidarDataset) and :518-565 (LidarInferenceDataset) on seeded pickled samples, numpy RNG seeded as in
+    tests/golden/make_golden.py::sec_cls_data: the resampling draws, the seven feature columns, both label kinds, the class counts."""
+    import pickle
+    from helpers import cls_sample_array
+    g = golden("cls_data")
+    D = sub("pointNet.datasets")
+    files = ["pc_81.pkl", "tower_82.pkl", "tower_83.pkl"]
+    for f, n, seed in zip(files, (300, 150, 200), (81, 82, 83)):
+        with open(tmp_path / f, "wb") as fh:
+            pickle.dump(cls_sample_array(synth, seed, n), fh)
+    for task in ("classification", "segmentation"):
+        for cs in (False, True):
+            ds = D.LidarDataset(str(tmp_path), task=task, number_of_points=200, files=files, fixed_num_points=True, c_sample=cs)
+            np.random.seed(17)
+            for i in range(len(files)):
+                pc, lab, fn = ds[i]
+                tag = f"{task[:3]}_{int(cs)}_{i}"
+                assert isinstance(pc, np.ndarray) and pc.dtype == np.float32 and pc.shape[1] == 7
+                assert np.array_equal(pc, g["ds_pc_" + tag]), tag
+                assert np.array_equal(np.asarray(lab), g["ds_lab_" + tag]), tag
+                assert fn == str(tmp_path / files[i])
+            assert [len(ds), ds.len_towers, ds.len_landscape] == g[f"ds_counts_{task[:3]}_{int(cs)}"].tolist()
+    inf = D.LidarInferenceDataset(str(tmp_path), files=files, c_sample=True)
+    for i in range(len(files)):
+        pc, fn = inf[i]
+        assert torch.is_tensor(pc) and pc.dtype == torch.float32
+        assert np.array_equal(pc.numpy(), g[f"inf_pc_{i}"])
+
+
+def test_collate_cls_padd_matches_reference(golden, synth):
+    """pointNet/collate_fns.py:58-113 with the python / torch RNGs seeded as in make_golden.py::sec_cls_data."""
+    import random
+    g = golden("cls_data")
+    C = sub("pointNet.collate_fns")
+    batch = []
+    for seed, n, w in [(91, 2048, 1), (92, 1500, 4), (93, 3000, 9)]:
+        win = synth.windows(seed, w, n)
+        pc = np.ascontiguousarray(win.transpose(1, 2, 0))
+        lab = synth.labels_for(win, seed).transpose(1, 0).copy()
+        cent = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], 0).astype(np.float32)
+        batch.append((pc, [seed % 2], f"f{seed}", cent, lab))
+    random.seed(6); torch.manual_seed(6)
+    data, tg, names, cents, seg = C.collate_cls_padd(batch)
+    assert list(data.shape) == g["c_data_shape"].tolist() and names == ["f91", "f92", "f93"]
+    assert np.array_equal(tg.numpy(), g["c_tg"])
+    assert np.array_equal(cents.numpy(), g["c_cents"])
+    assert np.allclose(data.double().sum(dim=(1, 2)).numpy(), g["c_data_sum"], rtol=0, atol=0)
+    assert np.array_equal(data[:, ::97, :, :].numpy(), g["c_data_probe"])
+    assert np.array_equal(seg[:, ::97, :].numpy(), g["c_seg_probe"])
+    assert np.array_equal(seg.sum(dim=1).numpy(), g["c_seg_sum"])
+    assert seg.dtype == torch.int64 and (seg[0, :, 1:] == -1).all()
