@@ -184,7 +184,6 @@ extern "C" int ampnet_pointnet_seg_fwd_f32(const float *const *layers_host, int 
                                            int n_classes, float *logits, float *feat_T, void *workspace,
                                            size_t workspace_bytes, void *stream)
 {
-    ampnet::SgemmValuScope valu_order;          // kernels.h: the fixtures of this path pin the VALU kernel's summation order
     Dims d;
     AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_seg_fwd_f32: variant %d (0 = pointnet.py, 1 = light_pointnet_256.py)", variant);
     AMPNET_REQUIRE(layers_host && x && logits && workspace, "ampnet_pointnet_seg_fwd_f32: null pointer");

@@ -518,7 +518,6 @@ extern "C" size_t ampnet_pointnet_seg_train_workspace_bytes(int variant, int B, 
 extern "C" int ampnet_pointnet_seg_train_fwd_f32(const float *const *layers_host, int variant, const float *x, int B, int N, int n_classes,
                                                  float *logits, float *feat_T, void *workspace, size_t workspace_bytes, void *stream)
 {
-    ampnet::SgemmValuScope valu_order;          // kernels.h: the fixtures of this path pin the VALU kernel's summation order
     Dims d;
     AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_seg_train_fwd_f32: variant %d", variant);
     AMPNET_REQUIRE(layers_host && x && logits && feat_T && workspace, "ampnet_pointnet_seg_train_fwd_f32: null pointer");
@@ -549,7 +548,6 @@ extern "C" int ampnet_pointnet_seg_bwd_f32(const float *const *layers_host, floa
                                            int n_classes, const float *dlogits, const float *d_feat_T, void *workspace, size_t workspace_bytes,
                                            void *stream)
 {
-    ampnet::SgemmValuScope valu_order;          // kernels.h: the fixtures of this path pin the VALU kernel's summation order
     Dims d;
     AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_seg_bwd_f32: variant %d", variant);
     AMPNET_REQUIRE(layers_host && grads_host && x && dlogits && workspace, "ampnet_pointnet_seg_bwd_f32: null pointer");
@@ -590,7 +588,6 @@ extern "C" int ampnet_pointnet_cls_fwd_f32(const float *const *layers_host, int 
                                            float drop_p, uint32_t seed, float *log_probs, float *feat_T, void *workspace, size_t workspace_bytes,
                                            void *stream)
 {
-    ampnet::SgemmValuScope valu_order;          // kernels.h: the fixtures of this path pin the VALU kernel's summation order
     Dims d;
     AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_cls_fwd_f32: variant %d", variant);
     AMPNET_REQUIRE(layers_host && x && log_probs && feat_T && workspace, "ampnet_pointnet_cls_fwd_f32: null pointer");
@@ -624,7 +621,6 @@ extern "C" int ampnet_pointnet_cls_bwd_f32(const float *const *layers_host, floa
                                            int n_classes, float drop_p, uint32_t seed, const float *d_log_probs, const float *d_feat_T,
                                            void *workspace, size_t workspace_bytes, void *stream)
 {
-    ampnet::SgemmValuScope valu_order;          // kernels.h: the fixtures of this path pin the VALU kernel's summation order
     Dims d;
     AMPNET_REQUIRE(dims_for(variant, &d), "ampnet_pointnet_cls_bwd_f32: variant %d", variant);
     AMPNET_REQUIRE(layers_host && grads_host && x && d_log_probs && workspace, "ampnet_pointnet_cls_bwd_f32: null pointer");

@@ -211,8 +211,7 @@ int pool_bwd(const PoolBwd &a, hipStream_t st)
 // fixed order -- a quarter of the dependent (load -> barrier -> multiply) trips per launch.
 constexpr int SG_SK = 4;
 constexpr int SG_KD = 32;               // depth of a k slice per group and trip.  (64 made the hot path's launches ~10 % shorter before they moved to
-                                       // sgemm_mfma below; this kernel now only serves the baseline PointNets, whose B = 4 fixtures were measured with
-                                       // the summation order of 32 -- kernels.h: SgemmValuScope)
+                                       // sgemm_mfma below; this kernel is now the AMPNET_SGEMM_VALU=1 A/B form only)
 
 struct SgProblem {
     int M, N, K, ta, tb, lda, ldb, ldc, accumulate;
@@ -438,10 +437,6 @@ __global__ __launch_bounds__(64 * SGM_WAVES) void sgemm_mfma_kernel(SgArgs args)
     }
 }
 
-static thread_local int tl_sgemm_valu = 0;
-SgemmValuScope::SgemmValuScope() { ++tl_sgemm_valu; }
-SgemmValuScope::~SgemmValuScope() { --tl_sgemm_valu; }
-
 static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
 {
     AMPNET_REQUIRE(n >= 1 && n <= SG_MAX_PROBLEMS, "sgemm_small: %d problems", n);
@@ -460,7 +455,7 @@ static int sgemm_launch(const SgProblem *probs, int n, hipStream_t st)
     if (n == 1) a.p[1] = a.p[0];
     // AMPNET_SGEMM_VALU=1: the VALU kernel (A/B timing, tests/test_small_gemm_gpu.py compares the two)
     static const bool valu_env = [] { const char *e = getenv("AMPNET_SGEMM_VALU"); return e && e[0] == '1'; }();
-    bool valu = valu_env || tl_sgemm_valu > 0;
+    bool valu = valu_env;
     for (int i = 0; i < n; ++i) valu = valu && !probs[i].mul && !probs[i].kscale;      // the multiply epilogue / k scaling live in the matrix-core kernel only
     if (valu) {
         ProfScope prof("sgemm_small", flops, bytes, st);

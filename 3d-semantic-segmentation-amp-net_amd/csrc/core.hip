@@ -1,6 +1,8 @@
 // core.hip -- error plumbing and version entry points of the C ABI (include/ampnet_hip.h).
 #include "common.h"
+#include <algorithm>
 #include <cstring>
+#include <iterator>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -106,13 +108,27 @@ int matrix_precision() { return g_matrix_precision; }
 namespace ampnet {
 namespace {
 std::mutex g_tag_mu;
-std::unordered_map<const void *, int> g_ws_tag;
+struct WsTag {
+    int mode;
+    unsigned long long serial;       // when the forward ran (for eviction)
+};
+std::unordered_map<const void *, WsTag> g_ws_tag;
+unsigned long long g_tag_serial = 0;
 }  // namespace
 void ws_tag_set(const void *ws, int mode)
 {
     std::lock_guard<std::mutex> lk(g_tag_mu);
-    if (g_ws_tag.size() > 4096) g_ws_tag.clear();       // workspaces come and go with the caller's allocator: bounded
-    g_ws_tag[ws] = mode;
+    if (g_ws_tag.size() >= 4096 && g_ws_tag.find(ws) == g_ws_tag.end()) {
+        // workspaces come and go with the caller's allocator: drop the OLDER half (never a wholesale clear -- the encoder's tag of this very
+        // step must survive the head's forward a moment later, or the backward would refuse a valid tape)
+        std::vector<unsigned long long> serials;
+        serials.reserve(g_ws_tag.size());
+        for (const auto &kv : g_ws_tag) serials.push_back(kv.second.serial);
+        std::nth_element(serials.begin(), serials.begin() + serials.size() / 2, serials.end());
+        const unsigned long long cut = serials[serials.size() / 2];
+        for (auto it = g_ws_tag.begin(); it != g_ws_tag.end();) it = it->second.serial < cut ? g_ws_tag.erase(it) : std::next(it);
+    }
+    g_ws_tag[ws] = WsTag{mode, ++g_tag_serial};
 }
 int ws_tag_check(const void *ws, const char *who)
 {
@@ -120,7 +136,7 @@ int ws_tag_check(const void *ws, const char *who)
     {
         std::lock_guard<std::mutex> lk(g_tag_mu);
         auto it = g_ws_tag.find(ws);
-        if (it != g_ws_tag.end()) have = it->second;
+        if (it != g_ws_tag.end()) have = it->second.mode;
     }
     if (have < 0) return fail(AMPNET_E_ARG, "%s: this forward workspace holds no train-mode forward of this process", who);
     // modes 0..2 keep the saved activations in fp32 (a backward in any of them may follow a forward in any of them: the operand rounding

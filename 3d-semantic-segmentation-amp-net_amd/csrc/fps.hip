@@ -131,11 +131,16 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
         // ragged batch (ampnet_fps_ragged_f32): cloud b = rows cloud_off[b] .. cloud_off[b + 1] of one [total, ld] array, its samples go to
         // idx[out_off[b] .. out_off[b + 1]); n <= T * P is the launcher's promise (the template is picked for the largest cloud)
         const int c0 = cloud_off[blockIdx.x], o0 = out_off[blockIdx.x];
+        const int n_launch = n;                      // max_n of the launch: registers (T * P) and the LDS image are sized for it
         n = cloud_off[blockIdx.x + 1] - c0;
         s = min(out_off[blockIdx.x + 1] - o0, n);
         cloud = xyz + (size_t)c0 * ld;
         out = idx + o0;
         if (s <= 0) return;                          // uniform per workgroup
+        if (n > n_launch) {                          // a cloud larger than the caller's max_n (the host cannot see device offsets): refuse it
+            if (tid == 0) out[0] = -1;               // instead of overrunning LDS; its first index reads -1
+            return;
+        }
     }
 
     // the P points of a thread as P / 2 PAIRS: differences, squares and the two sums are v_pk_add_f32 / v_pk_mul_f32 on a pair (correctly
@@ -248,11 +253,16 @@ __global__ __launch_bounds__(T) void fps_stream_kernel(float *__restrict__ soa, 
     int32_t *out = idx + (size_t)blockIdx.x * s;
     if (cloud_off) {                                 // ragged batch: the workspace holds 4 * n_b floats per cloud, in cloud order
         const int c0 = cloud_off[blockIdx.x], o0 = out_off[blockIdx.x];
+        const int n_launch = n;
         n = cloud_off[blockIdx.x + 1] - c0;
         s = min(out_off[blockIdx.x + 1] - o0, n);
         base = (size_t)c0 * 4;
         out = idx + o0;
         if (s <= 0) return;
+        if (n > n_launch) {                          // beyond the caller's max_n: refused like in fps_kernel (first index -1)
+            if (tid == 0) out[0] = -1;
+            return;
+        }
     }
     const float *X = soa + base, *Y = X + n, *Z = Y + n;
     float *D = soa + base + 3 * (size_t)n;

@@ -462,14 +462,8 @@ struct PooledWgrad {
 int pooled_wgrad(const PooledWgrad &a, hipStream_t st);
 
 // C[M, N] = op(A) * op(B) (+ C if accumulate); row-major, small problems (T-Net FC layers, attention projections)
-// While one of these is alive on the calling thread the small GEMMs run on the VALU kernel (sgemm_small_kernel) instead of the matrix-core one.
-// The baseline PointNets use it: their fixtures are B = 4 / B = 16 steps whose FC BatchNorms normalise over that many rows, where the ORDER
-// of an fp32 sum decides max-pool argmax ties and moves gradient norms by per cent (tests/diagnostics/diag_baseline_noise.py); the bars of
-// those fixtures were measured with this kernel's order, and the path is latency-bound either way (config 1 is [4, 512, 9]).
-struct SgemmValuScope {
-    SgemmValuScope();
-    ~SgemmValuScope();
-};
+// (AMPNET_SGEMM_VALU=1 selects the VALU kernel sgemm_small_kernel for an A/B; the matrix-core kernel sgemm_mfma serves every caller,
+// the baseline PointNets included: their fixtures are held to the reference's own float32-to-float64 distance, not to a summation order)
 int sgemm_small(int transA, int transB, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                 int accumulate, hipStream_t st);
 // backward of a linear layer Y = X W^T on [rows, *] activations, both products in ONE launch: dW [n_out, n_in] = G^T X, dX [rows, n_in] = G W

@@ -288,14 +288,26 @@ def small_gemm(A, B, trans_a=False, trans_b=False, out=None, accumulate=False, w
     N, Kb = (B.shape[0], B.shape[1]) if trans_b else (B.shape[1], B.shape[0])
     if K != Kb:
         raise _lib.AmpnetError(f"small_gemm: inner dimensions differ ({K} vs {Kb})")
+    if B.device != A.device:
+        raise _lib.AmpnetError(f"small_gemm: A is on {A.device}, B on {B.device}")
     if out is None:
+        if accumulate:
+            raise _lib.AmpnetError("small_gemm: accumulate=True adds into `out`, which was not given")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    elif (out.dtype != torch.float32 or out.dim() != 2 or out.device != A.device or out.shape[0] < M or out.shape[1] < N or out.stride(1) != 1
+          or out.stride(0) < N):
+        raise _lib.AmpnetError(f"small_gemm: out must be a float32 matrix on {A.device} with contiguous rows and at least {M} x {N} elements, "
+                               f"got {tuple(out.shape)} {out.dtype} on {out.device} strides {out.stride()}")
+    if k_scale is not None:
+        if not k_scale.is_cuda or k_scale.device != A.device or k_scale.numel() != K:
+            raise _lib.AmpnetError(f"small_gemm: k_scale must hold K = {K} values on {A.device}, got {k_scale.numel()} on {k_scale.device}")
+        k_scale = k_scale.contiguous().float()
     rs = torch.empty((M,), dtype=torch.float32, device=A.device) if want_row_sums else None
     with torch.cuda.device(A.device):
         vp = ctypes.c_void_p
         rc = _lib.lib().ampnet_small_gemm_f32(int(trans_a), int(trans_b), M, N, K, vp(A.data_ptr()), A.stride(0), vp(B.data_ptr()), B.stride(0),
                                               vp(out.data_ptr()), out.stride(0), int(accumulate), _lib.ptr(rs),
-                                              _lib.ptr(k_scale.contiguous().float()) if k_scale is not None else None, _lib.stream_ptr(A.device))
+                                              _lib.ptr(k_scale), _lib.stream_ptr(A.device))
     _lib.check(rc, "ampnet_small_gemm_f32")
     return (out, rs) if want_row_sums else out
 

@@ -217,7 +217,7 @@ def forward_backward(pointnet, att_net, x, t, centroids, class_w, reg_weight=0.0
     xd = torch.as_tensor(x).to(dev, non_blocking=True).float()
     B, W, N, _ = xd.shape
     targets_pc = torch.as_tensor(t).reshape(B, W * N)
-    tgd = targets_pc.to(dev, non_blocking=True)
+    tgd = targets_pc.to(dev, non_blocking=True).long()          # any integer dtype in (numpy int32 labels): the C ABI takes int64
     cent = torch.as_tensor(centroids).to(dev).float().contiguous() if centroids is not None else None
     Q, rows = B * W, B * W * N
     eg = _store(pointnet, P.ENC_PARAMS)

@@ -124,6 +124,17 @@ def roofline_from(rows, work_rows=None, tables=("pmc_traffic.json", "r03_pmc_cou
     per_ms = top["ms"] / top["calls"]
     intensity = top["flops"] / max(top["bytes"], 1.0)
     is_bf16 = top["name"].endswith(" bf16")
+    if top["name"].endswith(" x3"):
+        # split kernels (precision mode f32x3): every algorithmic product is SIX v_mfma_f32_32x32x16_bf16 partial products, so the matrix pipe
+        # executes 6 x the algorithmic flops; priced on those against the dense bf16 peak, the algorithmic rate stated beside it
+        alg = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
+        ach = 6.0 * alg
+        return dict(bound="mfma", kernel=top["name"], achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
+                    flops_counted="executed bf16 MFMA flops = 6 x algorithmic (three-term split of both operands, six exact partial products)",
+                    algorithmic_tflops=round(alg, 2), algorithmic_frac_of_f32_mfma_peak=round(alg / PEAK_MFMA_F32_TFLOPS, 4),
+                    traffic=pmc_traffic_for(top["name"], work_rows, tables[0]), mfma_busy=pmc_counters_for(top["name"], work_rows, tables),
+                    algorithmic_bytes=round(top["bytes"] / top["calls"]), launch_ms=round(per_ms, 4),
+                    launches=int(top["calls"]), share_of_step=round(top["ms"] / sum(r["ms"] for r in rows), 3))
     peak_tf = PEAK_MFMA_BF16_TFLOPS if is_bf16 else PEAK_MFMA_F32_TFLOPS
     if intensity >= peak_tf * 1e3 / PEAK_HBM_GBPS:
         ach = top["flops"] / top["calls"] / (per_ms * 1e-3) / 1e12
@@ -395,6 +406,75 @@ def train_loop_inclusive(enc, att, trainer_mod, B, dev, steps):
         dt = (time.perf_counter() - t0) / steps
     out["device_metrics"] = {"ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N_WIN * N_POINTS / dt, 1),
                              "accuracy_last_step": round(G.metrics_from_confusion(host[-1].numpy(), 5)[0], 4)}
+    return out
+
+
+def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=64, n_files=1024, workers=(4, 8, 16)):
+    """Training throughput THROUGH THE REAL LOADER (never `value`): one epoch of the package's epoch loop (amp_train._epoch, what
+    train_att runs: train_pointnet-attention.py:95-106, 216-217) over a synthetic dataset in the reference's on-disk format --
+    DataLoader workers running LidarKmeansDataset.__getitem__ (torch.load of kmeans_<name>.pt, noise-row removal, label mapping,
+    centroids) + collate_seq_padd (resampling to 2048 points, cluster padding to 9), pin_memory, prefetched upload, device-side
+    augmentation, the fused step.  n_files names point at n_distinct files of 2048 points x 1..9 clusters (a warm page cache, as in
+    every epoch after the first); steady-state ms per step = time between the first and the last batch handed to the step."""
+    import shutil
+    import tempfile
+    synth, A = sub("synthetic"), sub("pointNet.amp_train")
+    D, C = sub("pointNet.datasets"), sub("pointNet.collate_fns")
+    root = tempfile.mkdtemp(prefix="ampnet_epoch_")
+    out = {"note": "amp_train._epoch over DataLoader(LidarKmeansDataset, collate_seq_padd, pin_memory) + DevicePrefetcher; files on local disk, warm cache",
+           "files": n_files, "distinct_files": n_distinct, "batch": B, "steps_per_epoch": n_files // B, "resident_input_ms_per_step": round(resident_ms, 4)}
+    try:
+        paths = synth.write_dataset(root, n_train=n_distinct, n_val=0, n_test=0, n_points=N_POINTS, seed=7000, max_w=N_WIN)
+        base = open(os.path.join(paths["lists"], "train_seg_files.txt")).read().split()
+        names = []
+        for i in range(n_files):
+            src = base[i % n_distinct]
+            if i < n_distinct:
+                names.append(src)
+                continue
+            dst = f"rep{i}_{src}"
+            os.symlink(os.path.join(paths["data"], "kmeans_" + src), os.path.join(paths["data"], "kmeans_" + dst))
+            names.append(dst)
+        ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).to(dev), reduction="mean", ignore_index=-1)
+        opt_p, opt_a = trainer_mod.FusedAdam(enc.parameters(), lr=1e-3), trainer_mod.FusedAdam(att.parameters(), lr=1e-3)
+        ds = D.LidarKmeansDataset(paths["data"], task="segmentation", number_of_points=N_POINTS, files=names)
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = os.cpu_count() or 1
+        out["host_cpus"] = cpus
+
+        class Stamped:                       # the loader, with the time each batch was handed out
+            def __init__(self, loader):
+                self.loader, self.t = loader, []
+
+            def __len__(self):
+                return len(self.loader)
+
+            def __iter__(self):
+                for b in self.loader:
+                    self.t.append(time.perf_counter())
+                    yield b
+
+        for nw in workers:
+            if nw > cpus:
+                continue
+            loader = Stamped(torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=nw, drop_last=True,
+                                                         collate_fn=C.collate_seq_padd, pin_memory=True))
+            np.random.seed(0)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            m = A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 0)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            n = len(loader.t)
+            steady = (t1 - loader.t[0]) / n if n > 0 else float("nan")            # from the first batch's arrival to the end of the last step
+            out[f"workers_{nw}"] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
+                                    "points_per_s": round(B * N_WIN * N_POINTS / steady, 1) if n else None,
+                                    "step_share_of_wall": round(resident_ms * 1e-3 / steady, 3) if n else None,
+                                    "first_batch_after_s": round(loader.t[0] - t0, 3) if n else None, "train_loss": round(float(m["loss"]), 4)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
     return out
 
 
@@ -674,15 +754,21 @@ def main():
     # and in forward + fused backward (BASELINE.json configs[2] names bf16 MFMA; tests/test_bf16_gpu.py states what holds there)
     def precision_leg(prec, note):
         sub("_lib").set_matrix_precision(prec)
+        leg_losses = []
         try:
             for _ in range(2):
                 step()
             sync()
             t3 = time.perf_counter()
             for _ in range(args.steps):
-                step()
+                o = step()
+                leg_losses.append(torch.stack([o["ce"][0], o["reg"].reshape(-1)[0]]))      # device tensors: read after the clock stops
             sync()
             dt_bf = time.perf_counter() - t3
+            ll = torch.stack(leg_losses).cpu().numpy()
+            if not np.isfinite(ll).all():
+                print(f"bench.py: non-finite loss in the {prec} leg: {ll.tolist()}", file=sys.stderr, flush=True)
+                raise SystemExit(3)
             # the leg's own roofline: HIP events around every launch for a few steps in this mode
             L.ampnet_profile_enable(1)
             for _ in range(min(args.steps, 5)):
@@ -691,19 +777,22 @@ def main():
             rows_bf = profile_read()
             L.ampnet_profile_enable(0)
         finally:
-            sub("_lib").set_matrix_precision("fp32")
+            sub("_lib").set_matrix_precision(args.precision)
         if dist is not None:
             tt = torch.tensor([dt_bf], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_bf = float(tt.item())
-        tables = (f"r03_pmc_traffic_{prec}.json", f"r03_pmc_counters_{prec}.json")
+        tables = ("pmc_traffic.json", "r03_pmc_counters.json") if prec == "fp32" else (f"r03_pmc_traffic_{prec}.json", f"r03_pmc_counters_{prec}.json")
         return {"ms_per_step": round(dt_bf / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_bf, 1), "note": note,
-                "roofline": roofline_from(rows_bf, B * N_WIN * N_POINTS, tables, hbm_from_pmc=True),
+                "last_step": {"ce": float(ll[-1][0]), "reg": float(ll[-1][1])},
+                "roofline": roofline_from(rows_bf, B * N_WIN * N_POINTS, tables, hbm_from_pmc=prec != "fp32"),
                 "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / min(args.steps, 5), 4), tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 1),
                                         gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows_bf], key=lambda r: -r["ms_per_step"])[:5]}
 
-    bf16_leg = bf16_train_leg = bf16_store_leg = None
-    if mode == "train" and args.precision == "fp32":
+    bf16_leg = bf16_train_leg = bf16_store_leg = fp32_leg = None
+    if mode == "train" and args.precision == "f32x3":
+        fp32_leg = precision_leg("fp32", "the same step on exact fp32 MFMA (v_mfma_f32_32x32x2_f32) in every layer: the round-1 .. 3 headline mode")
+    if mode == "train" and args.precision in ("fp32", "f32x3"):
         bf16_store_leg = precision_leg("bf16_store", "bf16_train + the activations kept for the backward (nine encoder z tensors, z2 / z3 of the head) "
                                                      "stored as bf16; inputs, outputs, gradients, parameters, statistics f32; bar: tests/test_bf16_gpu.py")
         bf16_leg = precision_leg("bf16", "forward per-point layers on v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate); backward f32")
@@ -721,9 +810,10 @@ def main():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         ar_ms = (time.perf_counter() - t4) / args.steps * 1e3
-    incl = fps = infer = dp_probe = None
+    incl = fps = infer = dp_probe = epoch_leg = None
     if mode == "train" and world == 1 and not args.no_extra_legs:
         incl = train_loop_inclusive(enc, att, trainer_mod, B, dev, max(args.steps // 2, 3))
+        epoch_leg = train_att_epoch_leg(enc, att, trainer_mod, B, dev, dt / args.steps * 1e3)
         fps = fps_leg(dev, 16, max(args.steps // 2, 3), 1, 200, 0.0 if args.no_cpu_baseline else 5.0)
         fps["many_clouds"] = fps_many_leg(dev, args.steps, 210)
         infer = inference_leg(enc, att, dev, args.steps)
@@ -749,11 +839,12 @@ def main():
             "forward_ms_per_window": round((fwd_ms if fwd_ms is not None else dt / args.steps * 1e3) / (B * N_WIN), 5),
             "model_tflops": round(value * flop_pt / 1e12, 2),
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
-            "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
+            "fp32_mfma_mode": fp32_leg, "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
-            "train_loop_inclusive": incl, "fps": fps, "inference": infer, "data_parallel_host_cost": dp_probe,
+            "train_loop_inclusive": incl, "train_att_epoch": epoch_leg, "fps": fps, "inference": infer, "data_parallel_host_cost": dp_probe,
             "check": check,
-            "roofline": roofline_from(rows, B * N_WIN * N_POINTS),
+            "roofline": roofline_from(rows, B * N_WIN * N_POINTS, ("r04_pmc_traffic_f32x3.json", "r04_pmc_counters_f32x3.json") if args.precision == "f32x3"
+                                      else ("pmc_traffic.json", "r03_pmc_counters.json")),
             "kernels": sorted([dict(name=r["name"], ms_per_step=round(r["ms"] / args.steps, 4), launches_per_step=r["calls"] / args.steps,
                                     tflops=round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), gbps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1))
                                for r in rows], key=lambda r: -r["ms_per_step"])[:args.kernels],

@@ -63,7 +63,9 @@ int ampnet_fps_f32(const float *xyz, int n_clouds, int n, int ld, int s, int32_t
  * to the cloud's size) go to idx[out_off[b] ..) as indices RELATIVE to the cloud, selection order, first = 0.  cloud_off / out_off:
  * DEVICE int32 arrays of n_clouds + 1 ascending offsets; max_n = the largest cloud (picks the kernel: every cloud of the launch runs the
  * variant built for max_n, so callers bucket files by size class -- data_proc/sample_fps.py of the package does).  Same arithmetic, same
- * tie rule, bit-identical to ampnet_fps_f32 cloud by cloud.  max_n > AMPNET_FPS_RESIDENT_MAX needs ampnet_fps_ragged_workspace_bytes().  */
+ * tie rule, bit-identical to ampnet_fps_f32 cloud by cloud.  max_n > AMPNET_FPS_RESIDENT_MAX needs ampnet_fps_ragged_workspace_bytes().
+ * HARD PRECONDITION: max_n >= every cloud of the launch (registers and LDS are sized for it; the offsets live on the device, so the host
+ * cannot check).  A cloud that breaks it is refused inside the kernel: the first index of its output range reads -1, nothing else is written. */
 size_t ampnet_fps_ragged_workspace_bytes(int total_rows, int max_n);
 int ampnet_fps_ragged_f32(const float *rows, int ld, const int32_t *cloud_off, const int32_t *out_off, int n_clouds, int total_rows,
                           int max_n, int32_t *idx, void *workspace, size_t workspace_bytes, void *stream);

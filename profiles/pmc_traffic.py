@@ -48,9 +48,13 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None, fps_cases=None):
     for key, v in res.items():
         sym, grid = key.split("|grid=")
         name = None
-        m = re.match(r"ampnet::pw_gemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)[,>]", sym)   # <CIN, NT, PRO, POOL, BF, ...>
+        m = re.match(r"ampnet::pw_gemm_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)[,>]", sym)   # <CIN, NT, PRO, POOL, BF, ABF, ZBF, PIPE, ARG, X3, ...>
         if m:
-            name = f"pw_gemm<{m.group(1)},{32 * int(m.group(2))}>" + ("+pool" if m.group(4) == "true" else "+store") + (" bf16" if m.group(5) == "true" else "")
+            x3 = re.match(r"ampnet::pw_gemm_kernel<(?:[^,]+, ){9}true", sym) is not None                    # the three-term split kernels (mode f32x3)
+            name = f"pw_gemm<{m.group(1)},{32 * int(m.group(2))}>" + ("+pool" if m.group(4) == "true" else "+store") + (" x3" if x3 else (" bf16" if m.group(5) == "true" else ""))
+        m = re.match(r"ampnet::pw_bwd_x3_kernel<(true|false)>", sym)
+        if m:
+            name = "pw_bwd<128,128>" + ("+gram" if m.group(1) == "true" else "") + " x3"
         m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
         if m:
             name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "")

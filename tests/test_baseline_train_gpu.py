@@ -1,10 +1,7 @@
 """Baseline PointNet TRAINING on the HIP path (BASELINE.json config 1: batch 4, N = 512, 9 features, 5 classes)
 against what the reference's own train_loop (pointNet/baseline/train_segmentation.py:274-328) returned on the same seeded batch
-(tests/golden/baseline_train.npz, baseline_light_train.npz: made by tests/golden/make_golden.py:sec_baseline_train).
-The config-1 shape [4, 512, 9] keeps its "runs end to end, loss decreases" role with the loose step-2 bars that B = 4 allows; the
-B = 16 fixtures (test_baseline_train_loop_b16_matches_reference) carry the tight bars at both steps.
-Bars at B = 4: loss terms 1e-4 (step 1) / 2e-2 (step 2, behind one Adam update at B = 4); gradient norms and the small gradients stored in full 2e-2 of
-their norm (B = 4 rows in the T-Net FC BatchNorms: the reference's own fp32 noise, tests/test_step_gpu.py); parameter sums after Adam."""
+(tests/golden/baseline*_train_b4.npz and _b16.npz: made by tests/golden/make_golden.py:sec_baseline_train16, each with the reference's
+own float64 evaluation as the arbiter of what a float32 implementation can be held to)."""
 import os
 import sys
 
@@ -18,7 +15,6 @@ from conftest import sub                           # noqa: E402
 from helpers import baseline_state                 # noqa: E402
 
 pytestmark = pytest.mark.gpu
-STEP2_STABLE = {"conv_4.weight", "conv_4.bias", "bn_3.weight", "bn_3.bias", "conv_3.weight", "conv_2.weight"}   # bar 1e-1 at step 2
 
 
 def _net(synth, variant):
@@ -33,83 +29,15 @@ def _net(synth, variant):
     return net
 
 
+@pytest.mark.parametrize("batch", ["b4", "b16"])
 @pytest.mark.parametrize("variant", ["baseline_train", "baseline_light_train"])
-def test_baseline_train_loop_matches_reference(golden, synth, variant):
-    B = sub("pointNet.baseline_seg")
-    g = golden(variant)
-    net = _net(synth, variant)
-    x = synth.windows(81, 4, 512)
-    t = synth.labels_for(x, 81)
-    t[0, :40] = -1
-    ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).cuda(), reduction="mean", ignore_index=-1)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    losses, bad = [], []
-    for step in (1, 2):
-        np.random.seed(2000 + step)
-        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * 4)
-        m, tpc, preds, _ = B.train_loop(data, opt, ce, net, None, True, 0, 0)
-        # step 2 sits behind one Adam update: its first step moves every element by lr * sign(g), and with B = 4 rows in the T-Net FC
-        # BatchNorms the small gradients' signs are fp32 noise in ANY implementation (measured: ce 0.85 %, reg 0.7 % from the reference)
-        rt = 1e-4 if step == 1 else 2e-2
-        for k, key in (("ce", "ce_loss"), ("reg", "reg_loss"), ("loss", "loss")):
-            want = float(g[f"s{step}_{k}"].reshape(-1)[0])
-            assert abs(m[key].item() - want) <= rt * abs(want), (step, k, m[key].item(), want)
-        losses.append(m["loss"].item())
-        if step == 1:      # after an Adam step the argmax of this untrained model (near-tie logits) follows the sign noise: only step 1 is pinned
-            assert (preds.numpy() != g["s1_preds"]).mean() < 5e-3
-        gtot = np.sqrt(sum(float(g[k][0]) ** 2 for k in g.files if k.startswith(f"s{step}_gnorm/")))
-        for k, p in net.named_parameters():
-            gn = g[f"s{step}_gnorm/{k}"]
-            got = p.grad.double()
-            # step-2 gradients sit behind one Adam update (lr * sign(g) per element) and the B = 4 FC BatchNorms: float32 and float64 torch
-            # evaluations of this very graph then differ by 5 ... 31 % in the encoder's gradient norms and by <= 0.6 % only in the last
-            # layers of the head (tests/diagnostics/diag_baseline_step2.py) -- so step 2 pins those, step 1 pins every tensor
-            if step == 1 or k in STEP2_STABLE:
-                rt = 2e-2 if step == 1 else 1e-1
-                if abs(got.norm().item() - gn[0]) > rt * gn[0] + 1e-5 * gtot:
-                    bad.append((step, "gnorm", k, got.norm().item(), float(gn[0])))
-            key = f"s1_grad/{k}"
-            if step == 1 and key in g.files:
-                err = np.linalg.norm(got.cpu().numpy() - g[key].astype(np.float64))
-                if err > 2e-2 * gn[0] + 1e-5 * gtot:
-                    bad.append((step, "grad", k, err, float(gn[0])))
-            ps = g[f"s{step}_psum/{k}"]
-            # a bias in front of a BatchNorm has an analytically zero gradient: Adam divides rounding noise by its own magnitude and moves
-            # every element by +-lr in a direction that is noise (in the reference as well) -- |sum| can differ by lr per element and step;
-            # elsewhere a fraction of the elements (2 % at step 1, 10 % at step 2) may step the other way
-            frac = 0.02 if step == 1 else 0.10
-            atol = 1.1e-3 * step * p.numel() if gn[0] < 1e-6 * gtot else 2.1e-3 * step * max(min(3.0, p.numel()), frac * p.numel())
-            have = p.detach().double().abs().sum().item()
-            if abs(have - ps[1]) > 2e-4 * abs(ps[1]) + atol:
-                bad.append((step, "psum", k, have, float(ps[1])))
-        if step == 1:                  # running statistics after one step depend on the step-1 forward only: tight
-            sd1 = net.state_dict()
-            for k in sd1:
-                if "running" in k:
-                    np.testing.assert_allclose(sd1[k].cpu().numpy(), g[f"s1_buf/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
-    assert not bad, bad
-    assert losses[1] < losses[0]                                  # "runs end-to-end; loss decreases"
-    sd = net.state_dict()
-    for k in sd:
-        if "running" in k:
-            # after step 2: momentum 0.1 x the step-2 batch statistics, which scatter between float32 and float64 torch on this very graph by
-            # 10 ... 130 % (variances) and by up to 0.38 absolute (means of the T-Net FC BatchNorms over B = 4 rows) --
-            # tests/diagnostics/diag_baseline_step2.py; the statistics after step 1 are pinned to 1e-3 above
-            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"final_buf/{k}"], rtol=0.15, atol=0.1, err_msg=k)
-    assert int(net.bn_1.num_batches_tracked) == 2
-    np.random.seed(2009)
-    with torch.no_grad():
-        data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * 4)
-        m, _, preds, _ = B.train_loop(data, opt, ce, net, None, False, 0, 0)
-    want = float(g["eval_ce"].reshape(-1)[0])
-    assert abs(m["ce_loss"].item() - want) <= 3e-2 * abs(want)    # behind two noisy Adam steps
-
-
-@pytest.mark.parametrize("variant", ["baseline_train", "baseline_light_train"])
-def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
-    """The same two optimisation steps of the reference's train_loop at B = 16 (tests/golden/baseline*_train_b16.npz,
-    make_golden.py:sec_baseline_train16), which also holds the reference's OWN float64 evaluation of the two steps (its code unchanged,
-    torch's default dtype set to float64) as the arbiter.
+def test_baseline_train_loop_matches_reference(golden, synth, variant, batch):
+    """Two optimisation steps of the reference's train_loop (pointNet/baseline/train_segmentation.py:274-328) + one eval pass on a seeded
+    batch, at BASELINE.json config 1's own shape [4, 512, 9] and at B = 16 (tests/golden/baseline*_train_b4.npz / _b16.npz,
+    make_golden.py:sec_baseline_train16).  The fixtures also hold the reference's OWN float64 evaluation of the two steps (its code
+    unchanged, torch's default dtype set to float64) as the arbiter: every bar is a multiple of the reference's own float32-to-float64
+    distance plus a floor, not a property of one summation order (the round-3 B = 4 bars only passed with the VALU small-GEMM kernel's
+    order; the path runs on the matrix-core kernel now).  At B = 4 the run must also show config 1's "loss decreases".
 
     Step 1 (depends on the seeded weights only): loss terms 1e-4, every gradient norm and every gradient stored in full within 2e-2 of
     its norm, running statistics 1e-3, predictions.
@@ -121,7 +49,7 @@ def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
     3 x (the reference's own float32-to-float64 distance) + 2e-2 of its norm of the float64 gradient -- a bar that is 2e-2 wherever the
     reference is reproducible (the head's last layers) and as wide as the reference's own noise elsewhere."""
     B = sub("pointNet.baseline_seg")
-    g = golden(variant + "_b16")
+    g = golden(variant + "_" + batch)
     Bn, N = (int(v) for v in g["shape"])
     net = _net(synth, variant)
     x = synth.windows(83, Bn, N)
@@ -129,16 +57,18 @@ def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
     t[0, :40] = -1
     ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).cuda(), reduction="mean", ignore_index=-1)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    bad, worst, tight2 = [], {1: 0.0, 2: 0.0}, 0
+    bad, worst, tight2, losses = [], {1: 0.0, 2: 0.0}, 0, []
     for step in (1, 2):
         np.random.seed(2100 + step)
         data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
         m, tpc, preds, _ = B.train_loop(data, opt, ce, net, None, True, 0, 0)
-        rt = 1e-4 if step == 1 else 2e-3
+        losses.append(m["loss"].item())
         for k, key in (("ce", "ce_loss"), ("reg", "reg_loss"), ("loss", "loss")):
             want = float(g[f"s{step}_{k}64"].reshape(-1)[0])
-            if abs(m[key].item() - want) > rt * abs(want):
-                bad.append((step, k, m[key].item(), want))
+            own = abs(float(g[f"s{step}_{k}"].reshape(-1)[0]) - want)          # the reference's float32 run against its float64 run
+            rt = 1e-4 if step == 1 else 2e-3
+            if abs(m[key].item() - want) > rt * abs(want) + 3.0 * own:
+                bad.append((step, k, m[key].item(), want, own))
         self_mism = float((g[f"s{step}_preds"] != g[f"s{step}_preds64"]).mean())           # the reference against itself
         mism = float((preds.numpy() != g[f"s{step}_preds64"]).mean())
         if mism > 2.0 * self_mism + (5e-3 if step == 1 else 1e-2):
@@ -168,18 +98,22 @@ def test_baseline_train_loop_b16_matches_reference(golden, synth, variant):
         for k in sd:
             if "running" in k:
                 ref = g[f"s{step}_buf64/{k}"]
+                own = np.abs(g[f"s{step}_buf/{k}"].astype(np.float64) - ref).max()      # the reference against itself
                 d = np.abs(sd[k].cpu().numpy() - ref).max()
-                if d > rt_buf * max(1.0, np.abs(ref).max()):
-                    bad.append((step, "buf", k, float(d)))
+                if d > rt_buf * max(1.0, np.abs(ref).max()) + 3.0 * own:
+                    bad.append((step, "buf", k, float(d), float(own)))
     assert not bad, bad[:12]
-    print(f"{variant} B=16: worst relative distance of a gradient tensor from the reference's float64 run: step 1 {worst[1]:.2e}, "
+    if Bn == 4:
+        assert losses[1] < losses[0]                              # "runs end-to-end; loss decreases"
+    print(f"{variant} B={Bn}: worst relative distance of a gradient tensor from the reference's float64 run: step 1 {worst[1]:.2e}, "
           f"step 2 {worst[2]:.2e}; {tight2} step-2 tensors carry the plain 2e-2 bar")
     np.random.seed(2109)
     with torch.no_grad():
         data = (torch.from_numpy(x.copy()), torch.from_numpy(t.copy()), ["f"] * Bn)
         m, _, preds, _ = B.train_loop(data, opt, ce, net, None, False, 0, 0)
     want = float(g["eval_ce64"].reshape(-1)[0])
-    assert abs(m["ce_loss"].item() - want) <= 5e-3 * abs(want), (m["ce_loss"].item(), want)
+    own = abs(float(g["eval_ce"].reshape(-1)[0]) - want)
+    assert abs(m["ce_loss"].item() - want) <= 5e-3 * abs(want) + 3.0 * own, (m["ce_loss"].item(), want, own)
 
 
 def test_baseline_gradients_match_float64_autograd(synth):

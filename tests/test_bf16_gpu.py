@@ -397,3 +397,47 @@ def test_bf16_store_training_matches_fp32_miou_and_oracle_logits(synth, params):
     assert err <= 0.15 * max(span, 1.0), (err, span)
     assert mean_err <= 0.02 * max(span, 1.0), (mean_err, span)
     assert mism <= 0.02, mism
+
+
+def test_bf16_store_first_step_at_the_bench_shape(synth, params):
+    """The bf16 legs of bench.py are quoted at BASELINE.json configs[2]'s full size (B = 64 x 9 windows x 2048 points), where nothing
+    checked them (round-3 review): the FIRST step of the `bf16_store` mode on bench.py's rank-0 batch (seed 100, fresh modules, dropout
+    0.3) against the fp32 figures the bench pins (tests/golden/bench_pin.json) and against the ORACLE's float32 train-mode forward with
+    the same keep-masks (tests/golden/make_bench_pin.py::train_forward).
+    Stated bounds (bf16 operands through twelve layers, bf16-stored activations; fp32 statistics and loss): ce within 2e-3 relative, reg
+    within 2e-2 relative of the pinned fp32 values; logits mean |diff| <= 1e-2 and max |diff| <= 0.15 of the logit span vs the oracle;
+    every loss and gradient finite.  Measured values are printed.  Informational for bench.py all the same: `value` is never a bf16 step."""
+    import importlib.util
+    import json
+    T, L = sub("trainer"), sub("_lib")
+    spec = importlib.util.spec_from_file_location("make_bench_pin", os.path.join(ROOT, "tests", "golden", "make_bench_pin.py"))
+    pin_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin_mod)
+    B, N, W = 64, 2048, 9
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_pin.json")))["train_B64"]
+    try:
+        L.set_matrix_precision("bf16_store")
+        enc, att = _models(synth, params, pin_mod.DROP_P)
+        assert att.seed == pin_mod.ATT_SEED and att._step == 0
+        enc.train(); att.train()
+        pc, tg, cent, _ = synth.sample_batch(100, B, N, max_w=W)
+        x = torch.from_numpy(np.ascontiguousarray(pc.transpose(0, 3, 1, 2))).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(tg.transpose(0, 2, 1))).cuda()
+        cw = torch.tensor([1.0, 2.0, 2.0, 1.0, 1.0], device="cuda")
+        out = T.forward_backward(enc, att, x, t, torch.from_numpy(cent).cuda(), cw)
+        torch.cuda.synchronize()
+        ce, reg, logits = out["ce"][0].item(), out["reg"].item(), out["logits"].cpu()
+        assert np.isfinite(ce) and np.isfinite(reg)
+        assert all(torch.isfinite(p.grad).all() for m in (enc, att) for p in m.parameters())
+    finally:
+        L.set_matrix_precision("fp32")
+    want = pin_mod.train_forward(synth, params, B, pin_mod.ATT_SEED)
+    span = want["logits"].abs().max().item()
+    d = (logits - want["logits"]).abs()
+    print(f"bf16_store first step at B = 64: ce {ce:.6f} vs fp32 pin {pin['ce']:.6f} ({abs(ce - pin['ce']) / abs(pin['ce']):.2e}), reg {reg:.4f} vs "
+          f"{pin['reg']:.4f} ({abs(reg - pin['reg']) / abs(pin['reg']):.2e}); logits vs the oracle: mean |diff| {d.mean().item():.3e}, max {d.max().item():.3e} "
+          f"on a span of {span:.3g}")
+    assert abs(ce - pin["ce"]) <= 2e-3 * abs(pin["ce"]), (ce, pin["ce"])
+    assert abs(reg - pin["reg"]) <= 2e-2 * abs(pin["reg"]), (reg, pin["reg"])
+    assert d.mean().item() <= 1e-2 * max(span, 1.0), (d.mean().item(), span)
+    assert d.max().item() <= 0.15 * max(span, 1.0), (d.max().item(), span)

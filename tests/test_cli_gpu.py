@@ -35,7 +35,7 @@ def test_train_then_test_cli(synth, tmp_path):
         ck = torch.load(ck_path, map_location="cpu", weights_only=True)
         ep = {k: v.float() for k, v in ck["base_pointnet"].items() if "num_batches" not in k}
         hp = {k: v.float() for k, v in ck["segmen_net"].items() if "num_batches" not in k}
-        accs = []
+        accs, ious = [], {k: [] for k in ("bckg", "tower", "cables", "low_veg", "high_veg")}
         for name in open(os.path.join(paths["lists"], "test_seg_files.txt")).read().split():
             stem = name.split(".")[0]
             clusters = torch.load(os.path.join(paths["clusters"], stem + "_clusters_list.pkl"), weights_only=True)
@@ -49,7 +49,18 @@ def test_train_then_test_cli(synth, tmp_path):
             preds = O.predictions(logits).reshape(-1).numpy()
             tg = torch.cat(sub("utils.utils").get_labels([c.clone() for c in clusters])).numpy()
             accs.append(O.accuracy(preds, tg))
+            # per-file IoU of every class PRESENT in the file's targets (test_pointnet_att_segmen.py:192-219)
+            for c, k in enumerate(ious):
+                if (tg == c).any():
+                    ious[k].append(O.iou_obj(preds, tg, c))
         assert abs(res["accuracy"] - float(np.mean(accs))) < 2e-4      # a handful of fp32 argmax ties at most
+        # the CSV row's per-class IoU (mean over the files that hold the class) and mIoU (mean of the five class means, :256-258):
+        # the oracle's, up to the same handful of ties
+        for k, v in ious.items():
+            want = float(np.mean(v)) if v else float("nan")
+            assert (np.isnan(want) and np.isnan(res["iou"][k])) or abs(res["iou"][k] - want) < 1e-3, (k, res["iou"][k], want)
+        want_miou = float(np.mean([np.mean(ious[k]) for k in ("tower", "low_veg", "high_veg", "bckg", "cables")]))
+        assert (np.isnan(want_miou) and np.isnan(res["mean_iou"])) or abs(res["mean_iou"] - want_miou) < 1e-3, (res["mean_iou"], want_miou)
     finally:
         os.chdir(cwd)
 
