@@ -24,26 +24,48 @@ def _pad_last(t, width, mode):
     return torch.cat([t, tail], dim=-1)
 
 
+def _fill_padded(out, i, t, width, mode):
+    """out[i, ..., :w] = t, out[i, ..., w:] = the last slice of t ('replicate') or the constant `mode` -- _pad_last written into place."""
+    w = t.shape[-1]
+    out[i, ..., :w] = t
+    if w < width:
+        if mode == "replicate":
+            out[i, ..., w:] = t[..., -1:]
+        else:
+            out[i, ..., w:] = mode
+
+
 def collate_seq_padd(batch):
     """batch: list of (pc [n, 9, w] float, labels [n, w] int, filename, centroids [2, w] float)
-    -> (data [B, 2048, 9, 9] f32, targets [B, 2048, 9] i64, filenames, centroids [B, 9, 2] f32)."""
-    data, targets, names, cents = [], [], [], []
-    for pc, labels, name, cent in batch:
+    -> (data [B, 2048, 9, 9] f32, targets [B, 2048, 9] i64, filenames, centroids [B, 9, 2] f32).
+    The output tensors are allocated once and every sample is gathered / padded straight into its slice (the values and the random draws
+    are those of the reference's pad + stack; half the memory traffic of building padded per-sample copies first: this runs in the
+    DataLoader workers and was 93 ms per batch of 64, bench.py train_att_epoch)."""
+    B = len(batch)
+    feats = int(torch.as_tensor(batch[0][0]).shape[1]) if B else 9
+    data = torch.empty((B, N_POINTS, feats, MAX_WINDOWS), dtype=torch.float32)
+    targets = torch.empty((B, N_POINTS, MAX_WINDOWS), dtype=torch.int64)
+    cents = torch.empty((B, 2, 1, MAX_WINDOWS), dtype=torch.float32)
+    names = []
+    for i, (pc, labels, name, cent) in enumerate(batch):
         pc = torch.as_tensor(pc).float()
         labels = torch.as_tensor(labels).long()
         cent = torch.as_tensor(cent).float().unsqueeze(1)            # [2, 1, w]
         n = pc.shape[0]
+        if pc.shape[2] > MAX_WINDOWS:
+            raise ValueError(f"{name}: {pc.shape[2]} clusters, at most {MAX_WINDOWS} fit")     # (torch.stack of the reference fails here as well)
+        idx = None
         if n < N_POINTS:
             idx = torch.randint(0, n, (N_POINTS,))
-            pc, labels = pc[idx], labels[idx]
         elif n > N_POINTS:
-            idx = random.sample(range(n), N_POINTS)
-            pc, labels = pc[idx], labels[idx]
-        data.append(_pad_last(pc, MAX_WINDOWS, "replicate"))
-        targets.append(_pad_last(labels, MAX_WINDOWS, -1))
-        cents.append(_pad_last(cent, MAX_WINDOWS, "replicate"))
+            idx = torch.as_tensor(random.sample(range(n), N_POINTS))
+        if idx is not None:
+            pc, labels = pc.index_select(0, idx), labels.index_select(0, idx)
+        _fill_padded(data, i, pc, MAX_WINDOWS, "replicate")
+        _fill_padded(targets, i, labels, MAX_WINDOWS, -1)
+        _fill_padded(cents, i, cent, MAX_WINDOWS, "replicate")
         names.append(name)
-    return torch.stack(data, 0), torch.stack(targets, 0), names, torch.stack(cents, 0).view(-1, MAX_WINDOWS, 2)
+    return data, targets, names, cents.view(-1, MAX_WINDOWS, 2)
 
 
 def collate_cls_padd(batch):

@@ -54,9 +54,14 @@ class LidarKmeansDataset(data.Dataset):
         pc = np.asarray(pc)
         # a point ROW is dropped from every cluster as soon as one cluster carries a noise code in it
         # (np.delete on axis 0 with the row indices of np.where over [n, w]; datasets.py:339-350)
+        # (the reference deletes code by code; the rows that survive all six passes are the rows that carry none of the codes in any
+        # cluster, in their original order: one mask instead of six np.where / np.delete copies of the whole array)
+        codes = pc[:, 3, :]
+        drop = np.zeros(codes.shape[0], dtype=bool)
         for code in NOISE_CLASSES:
-            rows = np.where(pc[:, 3, :] == code)[0]
-            pc = np.delete(pc, rows, axis=0)
+            drop |= (codes == code).any(axis=1)
+        if drop.any():
+            pc = pc[~drop]
         labels = segmentation_labels(pc[:, 3, :])
         pc = np.concatenate((pc[:, :3, :], pc[:, 4:10, :]), axis=1)
         pc[:, 0, :] = pc[:, 0, :] * 2 - 1
