@@ -298,23 +298,36 @@ def inference_leg(enc, att, dev, steps):
     enc.eval(); att.eval()
     files = [synth.test_file_clusters(6000 + 50 * i, 18) for i in range(16)]
     L = sub("_lib").lib()
-    out = {"workload": "synthetic test files of 18 ragged clusters (2048 .. 2447 points each), eval forward + argmax, fp32"}
+    out = {"workload": "synthetic test files of 18 ragged clusters (2048 .. 2447 points each), eval forward + argmax, in the headline precision mode; "
+                       "*_device_metrics = as amp_test.test() runs it (labels and confusion counts on the device, one download per run)"}
     try:
-        for tag, group in (("batch1", 1), ("files_per_launch_4", 4), ("files_per_launch_16", 16)):
+        G = sub("utils.get_metrics")
+        for tag, group, on_dev in (("batch1", 1, False), ("files_per_launch_4", 4, False), ("files_per_launch_16", 16, False),
+                                   ("batch1_device_metrics", 1, True), ("files_per_launch_16_device_metrics", 16, True)):
             def run():
+                # on_dev: what amp_test.test() does -- predictions and labels stay on the device, one confusion-count kernel per file,
+                # ONE download per run; otherwise the reference's contract: every call returns its predictions and labels on the host
+                counts = []
                 if group == 1:
                     for cl, ce in files:
-                        A.segment_file(enc, att, cl, ce, dev)
+                        r = A.segment_file(enc, att, cl, ce, dev, device_outputs=on_dev)
+                        if on_dev:
+                            counts.append(G.confusion_device(r[0], r[1], 5))
                 else:
                     for g0 in range(0, len(files), group):
-                        A.segment_files(enc, att, files[g0:g0 + group], dev)
-            run()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(max(1, min(steps, 3))):
+                        for r in A.segment_files(enc, att, files[g0:g0 + group], dev, device_outputs=on_dev):
+                            if on_dev:
+                                counts.append(G.confusion_device(r[0], r[1], 5))
+                if on_dev:
+                    return torch.stack(counts).cpu()
+            for _ in range(2):                 # both page-locked staging buffers of the call exist (and are large enough) before the clock starts
                 run()
             torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t0) / max(1, min(steps, 3)) / len(files)
+            t0 = time.perf_counter()
+            for _ in range(max(1, min(steps, 4))):
+                run()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / max(1, min(steps, 4)) / len(files)
             pts = sum(int(c.shape[0]) for cl, _ in files for c in cl) / len(files)
             # launches per file: every ampnet kernel is counted by the event profiler's table when it is on (one pass, untimed)
             L.ampnet_profile_enable(1)
