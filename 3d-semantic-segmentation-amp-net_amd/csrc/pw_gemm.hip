@@ -429,26 +429,28 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     // VALU instructions do not overlap with fp32 MFMAs on this part -- tools/mfma_probe.hip -- so every epilogue instruction is
     // time taken from the matrix pipe).  z0 is only known after the wave's first tile of the block of rows: that tile starts at
     // bias and has z0 subtracted once it is known.
-    // Split kernels: the statistics run over ALL blocks of rows the workgroup walks (one shift z0 per wave -- its first row ever -- and
-    // one cross-wave merge at the end) instead of a merge per block: per block that merge (eight Chan steps in double per column by 128 of
-    // the 512 threads, between two barriers) took 39 % of the kernel (in-kernel stamps, tools/x3_stamps.py).  Per block only the pooled
-    // layers still combine their extremes across the waves.
+    // Per-WORKGROUP statistics (wg_stats: every train-mode point layer): the sums run over ALL blocks of rows the workgroup walks -- one
+    // shift z0 per wave (its first row ever), one cross-wave merge after the last block -- instead of a merge per block.  Per block that
+    // merge (a Chan step in double per wave and column by 128 threads, between two barriers) took 39 % of the split pooled kernel
+    // (in-kernel stamps, tools/x3_stamps.py) and was the round-3 regression of the fp32 one (the running merge into sRun came with the
+    // per-workgroup partials).  Per block only the pooled layers still combine their extremes across the waves.
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = cb0 + 32 * t + r;
-        if (!X3 || it == it_first) {
+        if (!wg_stats || it == it_first) {
             s_z0[t] = 0.f;
             s_sum2[t] = f32x2{0.f, 0.f};
             s_sq2[t] = f32x2{0.f, 0.f};
-            bias_v[t] = (!X3 && a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
-            // T-Net fc_3: the k x k output has the identity added (pointnetAtt.py:42-46): +1 on the columns i * (k + 1) of the k * k
-            if (!X3 && a.identity_k > 0 && col < a.cout && col % (a.identity_k + 1) == 0) bias_v[t] += 1.0f;
-            init_v[t] = bias_v[t];
         }
+        bias_v[t] = (!X3 && a.bias && col < a.cout) ? sgn[t] * a.bias[(size_t)(a.bias_win_stride ? pidx : 0) * a.bias_win_stride + col] : 0.f;
+        // T-Net fc_3: the k x k output has the identity added (pointnetAtt.py:42-46): +1 on the columns i * (k + 1) of the k * k
+        if (!X3 && a.identity_k > 0 && col < a.cout && col % (a.identity_k + 1) == 0) bias_v[t] += 1.0f;
         s_ext[t] = -__builtin_inff();
         s_arg[t] = -1;
     }
-    if (!X3 || it == it_first) s_cnt = 0;
+    if (!wg_stats || it == it_first) s_cnt = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) init_v[t] = bias_v[t] - s_z0[t];           // (z0 = 0 until the wave's first tile has set it)
 
     // The epilogue of one finished 32-row tile (accumulators `acc`, rows row0 .. row0 + valid - 1).  first: the wave's first tile of this block
     // of rows (its row 0 becomes the shift z0 of the statistics); fresh: the accumulators started at the bias (z0 was not known yet).
@@ -843,11 +845,14 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
             }
         }
 
-        finish_tile(acc, row0, valid, tile == wave, tile == wave);
+        {
+            const bool first_tile = wg_stats ? s_cnt == 0 : tile == wave;     // whose row 0 becomes the statistics' shift
+            finish_tile(acc, row0, valid, first_tile, first_tile);
+        }
     }
     }
 
-    const bool blk_stats = !X3 && do_stats;             // split kernels: statistics are merged once, after the last block
+    const bool blk_stats = !wg_stats && do_stats;       // per-workgroup statistics are merged once, after the last block
     if (!blk_stats && !POOL) continue;
     if constexpr (X3 && POOL) {
         // the block was this wave's alone: combine the two half-waves and write its extremes (empty block: -inf / -1, as pool_finalize expects)
@@ -930,18 +935,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         }
         const size_t o = (size_t)(q * a.chunks + chunk) * a.cout + col;
         const float sg = sg_own;
-        if (blk_stats && wg_stats) {
-            // merge this block of rows into the workgroup's running partial (the same thread owns column c in every block)
-            if (run_n == 0) {
-                sRun[2 * c] = mean;
-                sRun[2 * c + 1] = m2 < 0.0 ? 0.0 : m2;
-            } else if (n > 0.0) {
-                const double rn = (double)run_n, rmean = sRun[2 * c], nn = rn + n;
-                const double delta = mean - rmean, wgt = n * rcp_f64(nn);
-                sRun[2 * c] = rmean + delta * wgt;
-                sRun[2 * c + 1] += (m2 < 0.0 ? 0.0 : m2) + delta * delta * rn * wgt;
-            }
-        } else if (blk_stats) {
+        if (blk_stats) {
             a.part_sum[o] = sg * (float)mean;       // chunk mean (of z, not of the signed z')
             a.part_sq[o] = (float)(m2 < 0.0 ? 0.0 : m2);   // chunk sum of squared deviations
         }
@@ -957,8 +951,8 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     if (X3 && blockIdx.x == 0 && threadIdx.x == 0) g_pw_stamps[0] = (unsigned long long)stamp_n;
 #endif
     if (!(wg_stats && do_stats)) return;
-    if constexpr (X3) {
-        // the one cross-wave merge of the split kernels: per wave (rows, S1, S2, z0) over every block it walked -> Chan, fixed wave order
+    {
+        // the one cross-wave merge: per wave (rows, S1, S2, z0) over every block it walked -> Chan, fixed wave order
         float *red_f = sRed;
         int *red_n = reinterpret_cast<int *>(sRed + PW_NW * CB * 4) + PW_NW * CB;
         __syncthreads();                                        // the last block's pool merge has read the scratch

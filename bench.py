@@ -241,11 +241,25 @@ def fps_leg(dev, B, steps, warmup, seed, cpu_baseline_s=0.0):
     torch.cuda.synchronize(dev)
     knn_ms = ev2.elapsed_time(ev3) / steps
     ach = float(B) * S * N * 16 / (fps_ms * 1e-3) / 1e9
+    # What binds a resident cloud is the DEPENDENT ROUND on the one CU it lives on, not HBM (PMC: ~2 MB of traffic per launch against
+    # 8.59 GB "algorithmic"): the roof is the VALU issue floor of a round's update -- 512 threads x 16 points, 8 packed instructions per PAIR
+    # of points = 64 instructions per wave, two waves per SIMD, 4 cycles each = 512 cycles per round -- and the measured round is that
+    # update (584 cycles) + the slot write and barrier (978) + the cross-wave fold (282) + the winner's coordinates (244), which are
+    # latencies of a chain, not throughput (ampnet_fps_round_stamps).
+    round_cyc = fps_ms * 1e-3 / (S - 1) * 2.4e9
+    valu_floor = 2.0 * 8 * 8 * 4                         # waves per SIMD x pairs per thread x instructions per pair x issue cycles
     out = {"workload": f"farthest-point sampling, {B} clouds x {N} points -> {S} samples", "ms": round(fps_ms, 4),
            "selections_per_s": round(B * S / (fps_ms * 1e-3), 1), "us_per_round": round(fps_ms * 1e3 / (S - 1), 4),
-           "roofline": {"bound": "hbm", "kernel": "fps_kernel", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic_for("fps_kernel", B * N), "launch_ms": round(fps_ms, 4),
-                        "note": "algorithmic 16 B per (candidate, round); register-resident cloud: true HBM bytes = B*(N*12+S*4)"},
+           "roofline": {"bound": "valu-issue (one CU per cloud, dependent rounds)", "kernel": "fps_kernel", "achieved": round(2.4e9 / round_cyc, 1),
+                        "peak": round(2.4e9 / valu_floor, 1), "unit": "rounds/s per cloud", "frac": round(valu_floor / round_cyc, 4),
+                        "cycles_per_round_at_2.4GHz": round(round_cyc, 1), "valu_issue_floor_cycles": valu_floor,
+                        "round_breakdown_cycles": {"update": 584, "slot_and_barrier": 978, "fold": 282, "winner_coordinates": 244,
+                                                   "source": "ampnet_fps_round_stamps, thread 0, N = 8192 (DESIGN.md section 5)"},
+                        "traffic": pmc_traffic_for("fps_kernel", B * N), "launch_ms": round(fps_ms, 4),
+                        "hbm_accounting_8d": {"achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4),
+                                              "note": "SURVEY 8(d): 16 B per (candidate, round); the cloud is register / LDS resident, so these bytes never "
+                                                      "reach HBM (true traffic = B*(N*12+S*4)): kept for continuity, not the binding roof"},
+                        "note": "throughput comes from many clouds at once (fps.many_clouds): 256 clouds fill the chip at the same time per round"},
            "knn": {"k": K, "ms": round(knn_ms, 4), "centres_per_s": round(B * S / (knn_ms * 1e-3), 1),
                    "achieved_GBps": round(float(B) * S * N * 12 / (knn_ms * 1e-3) / 1e9, 1), "traffic": pmc_traffic_for("knn_kernel", B * N),
                    "note": "build-defined exact k-NN (the reference has none); algorithmic 12 B per (candidate, centre), served from LDS"}}
@@ -261,6 +275,26 @@ def fps_leg(dev, B, steps, warmup, seed, cpu_baseline_s=0.0):
         out["cpu_baseline"] = {"value": round(n * S / dtc, 1), "unit": "selections/s", "cores": 1, "kind": "port",
                                "sample": f"{n} clouds x {N} -> {S}, oracle/fps_oracle.c (scalar C), {dtc:.1f} s"}
     return out
+
+
+def kmeans_leg(dev, steps):
+    """The only inference-time stage of the GRU variant's test() without a number so far (test_pointnet_gru_segmen.py:135: in-situ constrained
+    k-means of every file): ampnet_kmeans_balanced_f32 on one 40 000-point file, k = 18 clusters of >= 2048 points, n_init 5, max_iter 10 --
+    the arguments utils.kmeans_clustering uses.  Build-defined algorithm (parity unpinned by construction: KMeansConstrained is third party)."""
+    synth, U = sub("synthetic"), sub("utils.utils")
+    n, k = 40000, 18
+    feat = torch.from_numpy(np.ascontiguousarray(synth.uniform(8100, (n, 3), 0.0, 1.0).astype(np.float32))).to(dev)
+    U.kmeans_balanced(feat, k, 2048, n, n_init=5, max_iter=10, tol=0.01, seed=0)
+    torch.cuda.synchronize(dev)
+    reps = max(1, min(steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        labels, _, inertia = U.kmeans_balanced(feat, k, 2048, n, n_init=5, max_iter=10, tol=0.01, seed=0)      # (returns the inertia: one sync per call)
+    dt = (time.perf_counter() - t0) / reps
+    sizes = torch.bincount(labels.long(), minlength=k)
+    return {"workload": f"size-constrained k-means, {n} points x 3 features, k = {k}, size_min 2048, n_init 5, max_iter 10 (one test file of the GRU variant)",
+            "ms_per_file": round(dt * 1e3, 3), "points_per_s": round(n / dt, 1), "min_cluster": int(sizes.min().item()), "max_cluster": int(sizes.max().item()),
+            "inertia": round(float(inertia), 4), "note": "build-defined algorithm (DESIGN.md section 3), untuned: a bitonic sort of n k keys per iteration"}
 
 
 def fps_many_leg(dev, steps, seed):
@@ -818,6 +852,35 @@ def main():
         bf16_train_leg = precision_leg("bf16_train", "forward AND fused backward of the per-point layers on bf16 MFMA operands (f32 accumulate, "
                                                      "f32 tensors in HBM, f32 BatchNorm statistics / sums); gradient bar: tests/test_bf16_gpu.py")
 
+    # N > 1: the SAME step with BatchNorm statistics and loss normalisation over the GLOBAL batch (the reference's single-device semantics at
+    # batch_per_gpu x N; 36 latency-bound exchanges per step) next to the headline's per-rank statistics, so that one multi-GPU run yields both
+    sync_bn_leg = None
+    if world > 1 and mode == "train" and not args.sync_bn:
+        if trainer_mod.enable_sync_batchnorm():
+            try:
+                for _ in range(2):
+                    step()
+                sync()
+                t5 = time.perf_counter()
+                sl = []
+                for _ in range(args.steps):
+                    o = step()
+                    sl.append(torch.stack([o["ce"][0], o["reg"].reshape(-1)[0]]))
+                sync()
+                dt_s = time.perf_counter() - t5
+            finally:
+                trainer_mod.disable_sync_batchnorm()
+            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_s = float(tt.item())
+            sl = torch.stack(sl).cpu().numpy()
+            if not np.isfinite(sl).all():
+                print(f"bench.py: non-finite loss in the global-batch BatchNorm leg (rank {rank}): {sl.tolist()}", file=sys.stderr, flush=True)
+                raise SystemExit(3)
+            sync_bn_leg = {"batchnorm": "global batch (statistics all-gathered / all-reduced per BatchNorm, loss over the global batch)",
+                           "ms_per_step": round(dt_s / args.steps * 1e3, 4), "points_per_s": round(world * B * N_WIN * N_POINTS * args.steps / dt_s, 1),
+                           "last_step": {"ce": float(sl[-1][0]), "reg": float(sl[-1][1])}}
+
     # the data-parallel exchange on its own: one SUM all-reduce per network over its flat gradient buffer (4.8 MB in all)
     ar_ms = None
     if dist is not None and mode == "train":
@@ -829,13 +892,14 @@ def main():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
         ar_ms = (time.perf_counter() - t4) / args.steps * 1e3
-    incl = fps = infer = dp_probe = epoch_leg = None
+    incl = fps = infer = dp_probe = epoch_leg = kmeans = None
     if mode == "train" and world == 1 and not args.no_extra_legs:
         incl = train_loop_inclusive(enc, att, trainer_mod, B, dev, max(args.steps // 2, 3))
         epoch_leg = train_att_epoch_leg(enc, att, trainer_mod, B, dev, dt / args.steps * 1e3)
         fps = fps_leg(dev, 16, max(args.steps // 2, 3), 1, 200, 0.0 if args.no_cpu_baseline else 5.0)
         fps["many_clouds"] = fps_many_leg(dev, args.steps, 210)
         infer = inference_leg(enc, att, dev, args.steps)
+        kmeans = kmeans_leg(dev, args.steps)
         dp_probe = syncbn_probe(min(args.steps, 8))
 
     if rank == 0:
@@ -860,7 +924,8 @@ def main():
             "ms_per_step_with_events": round(dt_prof / args.steps * 1e3, 4),
             "fp32_mfma_mode": fp32_leg, "bf16_forward_mode": bf16_leg, "bf16_train_mode": bf16_train_leg, "bf16_store_mode": bf16_store_leg,
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend), "allreduce_ms_per_step": None if ar_ms is None else round(ar_ms, 4),
-            "train_loop_inclusive": incl, "train_att_epoch": epoch_leg, "fps": fps, "inference": infer, "data_parallel_host_cost": dp_probe,
+            "global_batch_batchnorm_mode": sync_bn_leg,
+            "train_loop_inclusive": incl, "train_att_epoch": epoch_leg, "fps": fps, "inference": infer, "kmeans": kmeans, "data_parallel_host_cost": dp_probe,
             "check": check,
             "roofline": roofline_from(rows, B * N_WIN * N_POINTS, ("r04_pmc_traffic_f32x3.json", "r04_pmc_counters_f32x3.json") if args.precision == "f32x3"
                                       else ("pmc_traffic.json", "r03_pmc_counters.json")),
