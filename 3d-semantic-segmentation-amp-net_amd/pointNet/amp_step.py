@@ -80,6 +80,37 @@ def augment_batch_device(pc_clusters, targets, train, device):
     return x, t
 
 
+def augment_ragged_device(rb, train, device):
+    """augment_batch_device for a collate_fns.RaggedBatch: the same draws from numpy's RNG in the same order, ONE upload of the ragged
+    samples (less than half the bytes of the padded batch) and one kernel that resamples, pads, permutes, rotates and re-lays-out
+    (include/ampnet_hip.h: ampnet_collate_augment_f32) -> device x [B, W, N, 9] f32, t [B, W, N] i64, bit-identical to
+    augment_batch_device(*rb.to_padded()) (tests/test_augment_gpu.py)."""
+    import ctypes
+    B, N, W = len(rb), rb.n_points, rb.n_windows
+    cperm = np.arange(W)
+    np.random.shuffle(cperm)                                   # shuffle_clusters
+    r_angle = np.random.uniform() * 2 * np.pi
+    pperm = None
+    if train:
+        pperm = np.empty((W, N), dtype=np.int32)
+        for w in range(W):                                     # shuffle_data: one permutation per window
+            idx = np.arange(N)
+            np.random.shuffle(idx)
+            pperm[w] = idx
+    dev = torch.device(device)
+    rbd = rb if rb.is_cuda else rb.to(dev, non_blocking=True)
+    cpd = torch.from_numpy(cperm.astype(np.int32)).to(dev, non_blocking=True)
+    ppd = torch.from_numpy(pperm).to(dev, non_blocking=True) if pperm is not None else None
+    x = torch.empty((B, W, N, 9), dtype=torch.float32, device=dev)
+    t = torch.empty((B, W, N), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ampnet_collate_augment_f32(_lib.ptr(rbd.pts), _lib.ptr(rbd.lab), _lib.ptr(rbd.idx), _lib.ptr(rbd.meta), _lib.ptr(cpd), _lib.ptr(ppd),
+                                                   ctypes.c_double(float(np.cos(r_angle))), ctypes.c_double(float(np.sin(r_angle))),
+                                                   1 if train else 0, B, N, W, _lib.ptr(x), _lib.ptr(t), _lib.stream_ptr(dev))
+    _lib.check(rc, "ampnet_collate_augment_f32")
+    return x, t
+
+
 def forward_batch(pointnet, att_net, x, t, centroids, class_w=None, want_loss=True, want_preds=True):
     """x [B, W, N, 9] f32 (host or device), t [B, W, N] i64, centroids [B, W, 2].
     Returns dict(logits [B, C, W*N], preds [B, W*N], ce (device scalar tensor [2] or None), feat_T, targets_pc)."""
@@ -128,8 +159,14 @@ def train_loop(data, optimizer_pointnet, optimizer_att, ce_loss, pointnet, att_n
     pointnet.train(train)
     att_net.train(train)
     dev = next(pointnet.parameters()).device
+    from .collate_fns import RaggedBatch
+    ragged = isinstance(pc_clusters, RaggedBatch)                    # collate_seq_ragged: resampling / padding happen in the kernel
     if os.environ.get("AMPNET_HOST_AUG") == "1":
+        if ragged:
+            pc_clusters, targets = pc_clusters.to_padded()
         x, t = augment_batch(pc_clusters, targets, train)            # the numpy path (same draws, same batch)
+    elif ragged:
+        x, t = augment_ragged_device(pc_clusters, train, dev)
     else:
         x, t = augment_batch_device(pc_clusters, targets, train, dev)
     cw = _class_weights(ce_loss, dev)

@@ -18,9 +18,9 @@ import torch
 
 from ..trainer import FusedAdam, shard_indices
 from ..utils.get_metrics import get_accuracy, get_iou_obj
-from ..utils.utils import rm_padding, save_checkpoint_segmen_model
+from ..utils.utils import limit_host_threads, rm_padding, save_checkpoint_segmen_model
 from .amp_step import train_loop
-from .collate_fns import collate_seq_padd
+from .collate_fns import collate_seq_padd, collate_seq_ragged
 from .datasets import LidarKmeansDataset
 from .model.pointnetAtt import BasePointNet, SegmentationWithAttention
 
@@ -113,6 +113,7 @@ def train_att(task, dataset_folder, path_list_files, output_folder, n_points, ba
         raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
     start = time.time()
     rank, world, local = _dist_setup()
+    limit_host_threads(reserve=number_of_workers)        # the main process's torch pool next to the loader's workers (utils.host_cpu_budget)
     if world > 1 and (sync_bn if sync_bn is not None else os.environ.get("AMPNET_SYNC_BN") == "1"):
         from ..trainer import enable_sync_batchnorm
         enable_sync_batchnorm()
@@ -129,8 +130,12 @@ def train_att(task, dataset_folder, path_list_files, output_folder, n_points, ba
     val_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=val_files)
     # pin_memory: the collated batch (42 MB of points + 9 MB of labels at B = 64) lands in page-locked memory in the loader's pinning
     # thread, so train_loop's single upload runs at PCIe rate instead of through a pageable staging copy (bench.py: train_loop_inclusive)
+    # collate: the reference's collate_seq_padd builds the padded [B, 2048, 9, 9] batch in the workers (42 MB of gathers per batch of 64:
+    # the epoch then runs at the loader's pace, bench.py train_att_epoch); collate_seq_ragged makes the same draws and leaves resampling
+    # and padding to the augmentation kernel.  AMPNET_PADDED_COLLATE=1 (or the numpy augmentation path) selects the reference's.
+    padded = os.environ.get("AMPNET_PADDED_COLLATE") == "1" or os.environ.get("AMPNET_HOST_AUG") == "1"
     mk = lambda ds: torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=number_of_workers,   # noqa: E731
-                                                drop_last=True, collate_fn=collate_seq_padd, pin_memory=True)
+                                                drop_last=True, collate_fn=collate_seq_padd if padded else collate_seq_ragged, pin_memory=True)
     train_loader, val_loader = mk(train_ds), mk(val_ds)
     if rank == 0:
         print(f'Dataset folder: {dataset_folder}\nSamples for training: {len(train_ds)} (per rank), validation: {len(val_ds)}')

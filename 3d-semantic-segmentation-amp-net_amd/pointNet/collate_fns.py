@@ -96,3 +96,83 @@ def collate_cls_padd(batch):
         names.append(name)
     return (torch.stack(data, 0), torch.stack(targets, 0), names, torch.stack(cents, 0).view(-1, MAX_WINDOWS, 2),
             torch.stack(seg, 0))
+
+
+class RaggedBatch:
+    """What collate_seq_ragged hands to the training step instead of the padded [B, 2048, 9, 9] / [B, 2048, 9] pair: the samples as the
+    dataset returned them, concatenated, + the resampling map.  The padded batch is never built on the host; include/ampnet_hip.h:
+    ampnet_collate_augment_f32 gathers it on the device.  Tensors only (pin_memory / to work attribute by attribute)."""
+    __slots__ = ("pts", "lab", "idx", "meta", "n_points", "n_windows")
+
+    def __init__(self, pts, lab, idx, meta, n_points=N_POINTS, n_windows=MAX_WINDOWS):
+        self.pts, self.lab, self.idx, self.meta, self.n_points, self.n_windows = pts, lab, idx, meta, n_points, n_windows
+
+    def __len__(self):
+        return int(self.idx.shape[0])
+
+    def pin_memory(self):                    # DataLoader(pin_memory=True) calls this on custom batch types
+        return RaggedBatch(self.pts.pin_memory(), self.lab.pin_memory(), self.idx.pin_memory(), self.meta.pin_memory(), self.n_points, self.n_windows)
+
+    def to(self, device, non_blocking=False):
+        return RaggedBatch(*(t.to(device, non_blocking=non_blocking) for t in (self.pts, self.lab, self.idx, self.meta)), self.n_points, self.n_windows)
+
+    def record_stream(self, stream):
+        for t in (self.pts, self.lab, self.idx, self.meta):
+            if t.is_cuda:
+                t.record_stream(stream)
+
+    @property
+    def is_cuda(self):
+        return self.pts.is_cuda
+
+    def to_padded(self):
+        """The (data [B, N, 9, W] f32, targets [B, N, W] i64) pair collate_seq_padd builds -- host reference of what the device kernel
+        gathers (tests; AMPNET_HOST_AUG=1)."""
+        B, N, W = len(self), self.n_points, self.n_windows
+        data = torch.empty((B, N, 9, W), dtype=torch.float32)
+        targets = torch.empty((B, N, W), dtype=torch.int64)
+        meta = self.meta.cpu().tolist()
+        pts, lab, idx = self.pts.cpu(), self.lab.cpu(), self.idx.cpu().long()
+        for b, (n, w, po, lo) in enumerate(meta):
+            pc = pts[po:po + n * 9 * w].view(n, 9, w).index_select(0, idx[b])
+            lb = lab[lo:lo + n * w].view(n, w).index_select(0, idx[b]).long()
+            _fill_padded(data, b, pc, W, "replicate")
+            _fill_padded(targets, b, lb, W, -1)
+        return data, targets
+
+
+def collate_seq_ragged(batch):
+    """collate_seq_padd without its 42 MB of host gathers per batch: same arguments, same random draws in the same order (so a seeded
+    run resamples identically), but the result carries the samples RAGGED --
+        (RaggedBatch, None, filenames, centroids [B, 9, 2] f32)
+    and the resampling to 2048 points / padding to 9 clusters happens on the GPU inside the augmentation kernel
+    (amp_step.train_loop -> ampnet_collate_augment_f32).  RaggedBatch.to_padded() rebuilds collate_seq_padd's tensors exactly."""
+    B = len(batch)
+    pts, lab, names = [], [], []
+    idx = torch.empty((B, N_POINTS), dtype=torch.int32)
+    meta = torch.empty((B, 4), dtype=torch.int32)
+    cents = torch.empty((B, 2, 1, MAX_WINDOWS), dtype=torch.float32)
+    po = lo = 0
+    ramp = None
+    for i, (pc, labels, name, cent) in enumerate(batch):
+        pc = torch.as_tensor(pc).float()
+        labels = torch.as_tensor(labels)
+        n, feats, w = pc.shape
+        if feats != 9 or w > MAX_WINDOWS:
+            raise ValueError(f"{name}: expected [n, 9, w <= {MAX_WINDOWS}], got {tuple(pc.shape)}")
+        if n < N_POINTS:
+            idx[i] = torch.randint(0, n, (N_POINTS,)).to(torch.int32)
+        elif n > N_POINTS:
+            idx[i] = torch.as_tensor(random.sample(range(n), N_POINTS), dtype=torch.int32)
+        else:
+            if ramp is None:
+                ramp = torch.arange(N_POINTS, dtype=torch.int32)
+            idx[i] = ramp
+        pts.append(pc.reshape(-1))
+        lab.append(labels.reshape(-1).to(torch.int8))
+        meta[i, 0], meta[i, 1], meta[i, 2], meta[i, 3] = n, w, po, lo
+        po += n * 9 * w
+        lo += n * w
+        _fill_padded(cents, i, torch.as_tensor(cent).float().unsqueeze(1), MAX_WINDOWS, "replicate")
+        names.append(name)
+    return RaggedBatch(torch.cat(pts), torch.cat(lab), idx, meta), None, names, cents.view(-1, MAX_WINDOWS, 2)

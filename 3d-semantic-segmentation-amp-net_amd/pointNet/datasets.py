@@ -19,12 +19,22 @@ def segmentation_labels(codes):
     """ASPRS class codes -> {0 background, 1 tower (15), 2 lines (14), 3 low/medium vegetation (3, 4), 4 high vegetation (5)}
     (datasets.py:449-458; utils/utils.py:562-570)."""
     codes = torch.as_tensor(codes)
+    if codes.is_floating_point() or codes.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
+        # one table look-up instead of five masked assignments (codes outside 0 .. 255 and fractional codes are background, as before:
+        # only the exact values 15, 14, 3, 4, 5 map to a class)
+        ci = codes.to(torch.int64)
+        exact = (ci.to(codes.dtype) == codes) & (ci >= 0) & (ci <= 255)
+        return torch.where(exact, _LABEL_LUT[ci.clamp(0, 255)], torch.zeros((), dtype=torch.long))
     lab = torch.zeros(codes.shape, dtype=torch.long)
     lab[codes == 15] = 1
     lab[codes == 14] = 2
     lab[(codes == 3) | (codes == 4)] = 3
     lab[codes == 5] = 4
     return lab
+
+
+_LABEL_LUT = torch.zeros(256, dtype=torch.long)
+_LABEL_LUT[15], _LABEL_LUT[14], _LABEL_LUT[3], _LABEL_LUT[4], _LABEL_LUT[5] = 1, 2, 3, 3, 4
 
 
 class LidarKmeansDataset(data.Dataset):
@@ -50,7 +60,10 @@ class LidarKmeansDataset(data.Dataset):
         """-> (pc [n', 9, w] float32 ndarray, labels [n', w] LongTensor, filename, centroids [2, w] ndarray)
         for task == 'segmentation' (the AMP-Net path)."""
         filename = self.paths_files[index]
-        pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True)
+        try:                                  # the file mapped, not read: the rows that survive are copied once, below
+            pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True, mmap=True)
+        except (RuntimeError, ValueError, TypeError):       # legacy (non-zip) torch.save files cannot be mapped
+            pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True)
         pc = np.asarray(pc)
         # a point ROW is dropped from every cluster as soon as one cluster carries a noise code in it
         # (np.delete on axis 0 with the row indices of np.where over [n, w]; datasets.py:339-350)
@@ -64,8 +77,9 @@ class LidarKmeansDataset(data.Dataset):
             pc = pc[~drop]
         labels = segmentation_labels(pc[:, 3, :])
         pc = np.concatenate((pc[:, :3, :], pc[:, 4:10, :]), axis=1)
-        pc[:, 0, :] = pc[:, 0, :] * 2 - 1
-        pc[:, 1, :] = pc[:, 1, :] * 2 - 1
+        xy = pc[:, :2, :]
+        xy *= 2                                # x, y <- 2 v - 1 in place (the same two float32 roundings as v * 2 - 1)
+        xy -= 1
         centroids = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], axis=0) if self.get_centroids else None
         if self.task != 'segmentation':
             raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")

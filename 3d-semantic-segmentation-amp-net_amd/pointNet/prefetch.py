@@ -21,7 +21,7 @@ class DevicePrefetcher:
 
     def _upload(self, batch):
         with torch.cuda.stream(self.stream):
-            moved = tuple(x.to(self.device, non_blocking=True) if torch.is_tensor(x) else x for x in batch)
+            moved = tuple(x.to(self.device, non_blocking=True) if (torch.is_tensor(x) or hasattr(x, "record_stream")) else x for x in batch)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return moved, ev
@@ -42,6 +42,6 @@ class DevicePrefetcher:
         moved, ev = item
         cur.wait_event(ev)
         for x in moved:
-            if torch.is_tensor(x) and x.is_cuda:
+            if (torch.is_tensor(x) or hasattr(x, "record_stream")) and x.is_cuda:      # tensors and collate_fns.RaggedBatch
                 x.record_stream(cur)                 # allocated on the copy stream, consumed on the compute stream
         return moved

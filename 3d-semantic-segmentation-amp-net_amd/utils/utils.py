@@ -310,3 +310,36 @@ def save_checkpoint_segmen_model(name, task, epoch, epochs_since_improvement, ba
     }
     os.makedirs("pointNet/checkpoints", exist_ok=True)
     torch.save(state, "pointNet/checkpoints/model_" + name + ".pth")
+
+
+def host_cpu_budget():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (cpu.max / cfs_quota_us) -- a container that
+    SEES 256 hardware threads but is scheduled on 16 of them.  torch sizes its intra-op pool from the former: 256 threads spinning on a
+    16-CPU quota next to DataLoader workers is what made an epoch with 12 workers 30 x slower than with 4 (bench.py train_att_epoch)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, int(os.environ.get("AMPNET_CPU_THREADS", n))))
+
+
+def limit_host_threads(reserve=0):
+    """Sizes torch's intra-op pool of THIS process to the CPU budget minus `reserve` (the DataLoader workers); returns the budget."""
+    import torch
+    budget = host_cpu_budget()
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), budget - reserve)))
+    return budget

@@ -456,7 +456,7 @@ def train_loop_inclusive(enc, att, trainer_mod, B, dev, steps):
     return out
 
 
-def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=64, n_files=2048, workers=(4, 8, 14)):
+def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=64, n_files=3072, workers=(4, 8)):
     """Training throughput THROUGH THE REAL LOADER (never `value`): one epoch of the package's epoch loop (amp_train._epoch, what
     train_att runs: train_pointnet-attention.py:95-106, 216-217) over a synthetic dataset in the reference's on-disk format --
     DataLoader workers running LidarKmeansDataset.__getitem__ (torch.load of kmeans_<name>.pt, noise-row removal, label mapping,
@@ -468,7 +468,7 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
     synth, A = sub("synthetic"), sub("pointNet.amp_train")
     D, C = sub("pointNet.datasets"), sub("pointNet.collate_fns")
     root = tempfile.mkdtemp(prefix="ampnet_epoch_")
-    out = {"note": "amp_train._epoch over DataLoader(LidarKmeansDataset, collate_seq_padd, pin_memory) + DevicePrefetcher; files on local disk, warm cache",
+    out = {"note": "amp_train._epoch over DataLoader(LidarKmeansDataset, collate_seq_ragged | collate_seq_padd, pin_memory) + DevicePrefetcher; files on local disk, warm cache",
            "files": n_files, "distinct_files": n_distinct, "batch": B, "steps_per_epoch": n_files // B, "resident_input_ms_per_step": round(resident_ms, 4)}
     try:
         paths = synth.write_dataset(root, n_train=n_distinct, n_val=0, n_test=0, n_points=N_POINTS, seed=7000, max_w=N_WIN)
@@ -485,12 +485,10 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
         ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).to(dev), reduction="mean", ignore_index=-1)
         opt_p, opt_a = trainer_mod.FusedAdam(enc.parameters(), lr=1e-3), trainer_mod.FusedAdam(att.parameters(), lr=1e-3)
         ds = D.LidarKmeansDataset(paths["data"], task="segmentation", number_of_points=N_POINTS, files=names)
-        try:
-            cpus = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cpus = os.cpu_count() or 1
-        cpus = max(1, min(cpus, int(os.environ.get("AMPNET_CPU_THREADS", "16"))))     # the GPU box gives a 16-CPU share of a 256-thread host
+        U = sub("utils.utils")
+        cpus = U.host_cpu_budget()                     # affinity capped by the cgroup quota (the GPU box: a 16-CPU share of a 256-thread host)
         out["host_cpus"] = cpus
+        threads_before = torch.get_num_threads()
 
         class Stamped:                       # the loader, with the time each batch was handed out
             def __init__(self, loader):
@@ -504,12 +502,15 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
                     self.t.append(time.perf_counter())
                     yield b
 
-        for nw in workers:
+        # ragged = the package's loader (collate_seq_ragged: the reference's random draws, resampling / padding inside the augmentation
+        # kernel, 20 MB per batch); padded = the reference's collate_seq_padd in the workers (51 MB per batch), one worker count for comparison
+        for nw, kind in [(w, "ragged") for w in workers] + [(4, "padded")]:
             if nw > cpus:
                 continue
             loader = Stamped(torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=nw, drop_last=True,
-                                                         collate_fn=C.collate_seq_padd, pin_memory=True))
+                                                         collate_fn=C.collate_seq_ragged if kind == "ragged" else C.collate_seq_padd, pin_memory=True))
             np.random.seed(0)
+            torch.set_num_threads(max(1, min(threads_before, cpus - nw)))      # as train_att does (limit_host_threads): the pool next to nw workers
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             m = A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 0)
@@ -519,12 +520,16 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
             # steady state: the second half of the epoch (the first batches were prefetched while the workers started up)
             h = n // 2
             steady = (t1 - loader.t[h]) / (n - h) if n > 1 else float("nan")
-            out[f"workers_{nw}"] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
+            out[f"workers_{nw}" + ("" if kind == "ragged" else "_padded_collate")] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
                                     "points_per_s": round(B * N_WIN * N_POINTS / steady, 1) if n else None,
                                     "step_share_of_wall": round(resident_ms * 1e-3 / steady, 3) if n else None,
                                     "first_batch_after_s": round(loader.t[0] - t0, 3) if n else None, "train_loss": round(float(m["loss"]), 4)}
     finally:
         shutil.rmtree(root, ignore_errors=True)
+        try:
+            torch.set_num_threads(threads_before)
+        except Exception:
+            pass
     return out
 
 

@@ -273,6 +273,23 @@ int ampnet_small_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const f
 int ampnet_augment_f32(const float *pc, const long long *targets, const int32_t *cluster_perm, const int32_t *point_perm,
                        double cos_a, double sin_a, int rotate, int B, int N, int W, float *x_out, long long *t_out, void *stream);
 
+/* ---- a9 + a8 on the device: collate_seq_padd's resampling / padding fused into the augmentation kernel --------------------
+ * replaces, together with the package's collate_seq_ragged (pointNet/collate_fns.py), the host work of pointNet/collate_fns.py:33-45
+ * (every sample gathered to exactly N = 2048 points, the cluster axis padded to W = 9 by replicating the last cluster, targets padded
+ * with -1) -- in the reference this runs in the DataLoader workers on 42 MB per batch of 64 and is what a train epoch waits for
+ * (bench.py: train_att_epoch).  The workers hand over the RAGGED samples and the resampling map instead:
+ *   pts     float32: sample b = [n_b, 9, w_b] (as LidarKmeansDataset returns it) at element offset meta[b][2]
+ *   labels  int8   : sample b = [n_b, w_b] segmentation labels 0 .. 4 at element offset meta[b][3]
+ *   idx     int32 [B, N]: padded row p of sample b is its own row idx[b][p] (the draws of collate_seq_padd: torch.randint when
+ *                         n_b < N, random.sample when n_b > N, the identity when n_b == N)
+ *   meta    int32 [B, 4]: n_b, w_b, pts offset, labels offset
+ * and the kernel writes what ampnet_augment_f32 would have written for the padded batch, bit for bit (tests/test_augment_gpu.py):
+ *   x_out[b, w, n, f] = pts_b[idx[b][pp], f, min(cw, w_b - 1)],  t_out[b, w, n] = cw < w_b ? labels_b[idx[b][pp], cw] : -1,
+ *   cw = cluster_perm[w], pp = point_perm[w, n] (NULL = n), then the z-rotation as above.  All arrays on the device.          */
+int ampnet_collate_augment_f32(const float *pts, const signed char *labels, const int32_t *idx, const int32_t *meta,
+                               const int32_t *cluster_perm, const int32_t *point_perm, double cos_a, double sin_a, int rotate,
+                               int B, int N, int W, float *x_out, long long *t_out, void *stream);
+
 /* ---- k-NN grouping of FPS centres (BUILD-DEFINED; BASELINE.json north_star / config 5) ------------------------------
  * The reference has no k-NN or ball query: nothing is replaced, parity against it is "unpinned"; the spec
  * below is pinned by oracle/fps_oracle.py:knn_indices.

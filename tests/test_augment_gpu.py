@@ -55,3 +55,32 @@ def test_train_loop_device_and_host_pipelines_agree(synth, params, monkeypatch):
         m, tpc, preds, _ = S.train_loop(data, _NoOpt(), _NoOpt(), ce, enc, att, None, "segmentation", False, 0, 0)
         res.append((m["loss"].item(), tpc.numpy().copy(), preds.numpy().copy()))
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_ragged_collate_plus_device_gather_equals_padded_path(synth, train):
+    """include/ampnet_hip.h: ampnet_collate_augment_f32 -- the resampling to 2048 points and the padding to 9 clusters that collate_seq_padd
+    does on the host (pointNet/collate_fns.py:33-45), done inside the augmentation kernel from the ragged batch of collate_seq_ragged: the
+    device tensors must be BIT-identical to collate_seq_padd -> ampnet_augment_f32 under the same python / torch / numpy seeds (fewer
+    points than 2048, more, exactly 2048; 1 .. 9 clusters)."""
+    import random
+    C, S = sub("pointNet.collate_fns"), sub("pointNet.amp_step")
+    batch = []
+    for seed, n, w in [(161, 2048, 1), (162, 2048, 3), (163, 1500, 5), (164, 3000, 9), (165, 2048, 9), (166, 700, 2)]:
+        win = synth.windows(seed, w, n)
+        pc = np.ascontiguousarray(win.transpose(1, 2, 0))
+        lab = synth.labels_for(win, seed).transpose(1, 0).copy()
+        cent = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], 0).astype(np.float32)
+        batch.append((pc, lab, f"f{seed}", cent))
+    random.seed(9); torch.manual_seed(9)
+    data, tg, _, cents = C.collate_seq_padd(batch)
+    random.seed(9); torch.manual_seed(9)
+    rb, _, _, cents2 = C.collate_seq_ragged(batch)
+    assert torch.equal(cents, cents2)
+    np.random.seed(31)
+    x1, t1 = S.augment_batch_device(data, tg, train, "cuda")
+    np.random.seed(31)
+    x2, t2 = S.augment_ragged_device(rb, train, "cuda")
+    assert torch.equal(x1, x2), f"{(x1 != x2).sum().item()} of {x1.numel()} values differ"
+    assert torch.equal(t1, t2)
+    assert (t2 == -1).any() and x2.shape == (6, 9, 2048, 9)

@@ -243,3 +243,32 @@ def test_collate_cls_padd_matches_reference(golden, synth):
     assert np.array_equal(seg[:, ::97, :].numpy(), g["c_seg_probe"])
     assert np.array_equal(seg.sum(dim=1).numpy(), g["c_seg_sum"])
     assert seg.dtype == torch.int64 and (seg[0, :, 1:] == -1).all()
+
+
+def test_collate_seq_ragged_is_collate_seq_padd_unpadded(golden, synth):
+    """collate_seq_ragged (the package's loader-side collate: no resampling / padding copies on the host) makes collate_seq_padd's random
+    draws in its order and carries exactly its information: RaggedBatch.to_padded() rebuilds the padded tensors bit for bit -- checked
+    against collate_seq_padd run with the same seeds AND against the reference's own output (tests/golden/collate.npz)."""
+    g = golden("collate")
+    C = sub("pointNet.collate_fns")
+    batch = []
+    for seed, n, w in [(61, 2048, 1), (62, 2048, 3), (63, 1500, 5), (64, 3000, 9), (65, 2048, 9)]:
+        win = synth.windows(seed, w, n)
+        pc = np.ascontiguousarray(win.transpose(1, 2, 0))
+        lab = synth.labels_for(win, seed).transpose(1, 0).copy()
+        cent = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], 0).astype(np.float32)
+        batch.append((pc, lab, f"f{seed}", cent))
+    random.seed(5); torch.manual_seed(5)
+    data, tg, names, cents = C.collate_seq_padd(batch)
+    random.seed(5); torch.manual_seed(5)
+    rb, none, names2, cents2 = C.collate_seq_ragged(batch)
+    assert none is None and names2 == names and torch.equal(cents2, cents)
+    assert rb.pts.dtype == torch.float32 and rb.lab.dtype == torch.int8 and rb.idx.dtype == torch.int32 and tuple(rb.meta.shape) == (5, 4)
+    assert rb.pts.numel() == sum(n * 9 * w for _, n, w in [(0, 2048, 1), (0, 2048, 3), (0, 1500, 5), (0, 3000, 9), (0, 2048, 9)])
+    d2, t2 = rb.to_padded()
+    assert torch.equal(d2, data) and torch.equal(t2, tg)
+    assert np.array_equal(d2[:, ::97, :, :].numpy(), g["data_probe"]) and np.array_equal(t2[:, ::97, :].numpy(), g["tg_probe"])
+    assert np.array_equal(cents2.numpy(), g["cents"])
+    # a DataLoader moves it like a tensor batch: pickling (worker -> main), to()
+    rb2 = pickle.loads(pickle.dumps(rb))
+    assert torch.equal(rb2.pts, rb.pts) and torch.equal(rb2.idx, rb.idx) and len(rb2) == 5
