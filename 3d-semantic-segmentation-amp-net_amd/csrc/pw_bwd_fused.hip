@@ -579,7 +579,9 @@ static int launch_fused_x(const PwBwd &a, hipStream_t st)
         attr_set = true;
     }
     char name[64];
-    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s", CX, CY, a.g.act ? "+gram" : "");
+    // one event name per kernel symbol (the rocprofv3 stats and bench.py's table then name the same thing): +gram, input without activation
+    // (lin), with an addend (+add), with dropout (+drop)
+    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s%s%s%s", CX, CY, a.g.act ? "+gram" : "", YACT ? "" : " lin", ADD ? "+add" : "", DROP ? "+drop" : "");
     const double rows = (double)a.rows_hint;
     const bool same = a.g.act && a.g.z == a.prev.z;
     // flops the launch executes: the symmetric Gram form multiplies 10 of the 16 tiles

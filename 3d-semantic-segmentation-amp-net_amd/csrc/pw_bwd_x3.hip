@@ -27,6 +27,18 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// Development probe (tools/build_stamps.sh, tools/x3_stamps.py bwd): wave 0 (W role) and wave 4 (D role) of workgroup 0 record (label, cycle)
+#ifdef AMPNET_PW_STAMPS
+__device__ unsigned long long g_bx_stamps[2][2048];
+#define BX_STAMP(id)                                                                                             \
+    do {                                                                                                         \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256) && stamp_n < 2000)                        \
+            g_bx_stamps[threadIdx.x >> 8][1 + stamp_n++] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xffffffffffffull); \
+    } while (0)
+#else
+#define BX_STAMP(id) do { } while (0)
+#endif
+
 constexpr int X3B_THREADS = 512;
 constexpr int X3B_ITEM_ROWS = 256;      // must equal pw_bwd_item_rows() (the host sizes per-window shares with it)
 
@@ -98,9 +110,12 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     constexpr int LDZ = CY + 4;                     // fp32 row of the activated-input tile
     constexpr int TYN = CY / 32;
     constexpr int TXW = 2, TYW = 2;                 // W role: 2 x 2 tiles per wave
-    constexpr int STAGE = X3B_THREADS;
-    constexpr int QX = CX / 4, SX = STAGE / QX;     // 32 channel quads, 16 row groups
-    constexpr int NIX = ROWS / SX;                  // 2 quads per thread and tensor
+    // Gram form: the four W waves stage (their role is the lighter one: no epilogue, no stores), the D waves only multiply, mask and store --
+    // with all eight staging, the D wave's products + epilogue (4600 cycles per block) and then its staging (2000) were the block's critical
+    // path while the W wave waited at the barrier (in-kernel stamps, tools/x3_stamps.py).  Dense form: everybody stages (three tensors).
+    constexpr int STAGE = GRAM ? X3B_THREADS / 2 : X3B_THREADS;
+    constexpr int QX = CX / 4, SX = STAGE / QX;     // 32 channel quads, 8 (Gram) or 16 row groups
+    constexpr int NIX = ROWS / SX;                  // 4 (Gram) or 2 quads per staging thread and tensor
     constexpr int IMG = ROWS * LDG;                 // elements of one image of one buffer
     static_assert(CX == CY && LDG == LDY && (ROWS / 32) * TYN == 4, "one dgrad tile per D wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -119,7 +134,8 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     const int ipb = a.items_per_block > 0 ? a.items_per_block : (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
     const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
 
-    const int cqx = tid % QX, rsx = tid / QX;
+    const int cqx = tid % QX, rsx = (tid % STAGE) / QX;
+    const bool stager = tid < STAGE;                 // (Gram form: waves 0 .. 3 = the W role)
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
     if (!GRAM && a.fin_part_a) {
         // the BatchNorm-backward constants of this layer from the partial sums its producer left (pw_bwd_fused.hip: fin_*)
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     if (!more2) nx2 = nxt;
     Regs S0, S1;
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every constant has landed before the loop (see pw_bwd_fused.hip)
-    if (live) {
+    if (live && stager) {
         load_regs(cur, S0);
         if (NSETS == 2) load_regs(nxt, S1);
         write_lds(0, cur, S0);
@@ -336,8 +352,26 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     int buf = 0;
     // one block of rows: compute block n from LDS, write block n + 1 (register set A) into the other buffer, refill A.  The two roles run
     // the loop as two separate instantiations (role_tag): every wait is then a static count of the role's own younger memory operations.
+    [[maybe_unused]] int stamp_n = 0;
     auto step = [&](Regs &A, auto role_tag) {
         constexpr bool W_ROLE = decltype(role_tag)::value;
+        BX_STAMP(1);                                   // block begins
+        // Gram form: the W wave stages block n + 1 FIRST and multiplies block n afterwards, the D wave multiplies first and runs its epilogue
+        // afterwards -- so on every SIMD one wave's VALU phase (staging / epilogue) lies under the other's MFMA phase.  With both roles
+        // multiplying first the matrix pipe idled for the second half of every block (stamps: products done at 3100 of 5850 cycles).
+        Pos nx3 = nx2;
+        bool more3 = false;
+        if constexpr (NSETS == 2) {
+            more3 = more2 && advance(nx3);
+            if (!more3) nx3 = nx2;
+#ifndef X3B_NO_SKEW                             // (A/B build switch, tools/ab_lib.sh: the W wave stages AFTER its products)
+            if (W_ROLE && GRAM) {
+                if (more1) write_lds(buf ^ 1, nxt, A);
+                load_regs(nx3, A);
+                BX_STAMP(3);                           // next block staged
+            }
+#endif
+        }
         // the buffer index stays a run-time scalar: folded (the loop alternates two step bodies) every LDS address of both buffers is hoisted
         // into a register of its own, ~60 of them, and they spill into the loop
         int bsel = buf;
@@ -345,7 +379,35 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
         const __bf16 *g = sG + bsel * 3 * IMG;
         const __bf16 *y = GRAM ? g : sY + bsel * 3 * IMG;
         const float *z = sZ + bsel * ROWS * LDZ;
-        if constexpr (W_ROLE) {
+        if constexpr (W_ROLE && GRAM) {
+            // the Gram matrix is symmetric: the four W waves own the 10 tiles of its upper triangle and mirror them at the flush -- waves 0 / 1
+            // the three tiles over column blocks {0, 1} / {2, 3}: (B0,B0) (B0,B1) (B1,B1), waves 2 / 3 the tiles (0,c) (1,c) with c = 2 / 3.
+            // An operand of a tile and an operand of another are the same registers: 18 / 12 MFMAs per wave and k step instead of 24.
+#pragma unroll
+            for (int s2 = 0; s2 < ROWS / 16; ++s2) {
+                if (ww < 2) {
+                    bf16x8 c0[3], c1[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        c0[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww), lane);
+                        c1[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww + 1), lane);
+                    }
+                    mfma6(acc_w[0][0], c0, c0);
+                    mfma6(acc_w[0][1], c0, c1);
+                    mfma6(acc_w[1][1], c1, c1);
+                } else {
+                    bf16x8 c0[3], c1[3], c2[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        c0[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 0, lane);
+                        c1[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32, lane);
+                        c2[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * ww, lane);
+                    }
+                    mfma6(acc_w[0][0], c0, c2);
+                    mfma6(acc_w[1][0], c1, c2);
+                }
+            }
+        } else if constexpr (W_ROLE) {
 #pragma unroll
             for (int s2 = 0; s2 < ROWS / 16; ++s2) {
                 bf16x8 xa[TXW][3], yb[TYW][3];
@@ -369,16 +431,25 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = c_b;
             const __bf16 *ga = g + r * LDG + 8 * h;
-#pragma unroll
-            for (int s2 = 0; s2 < CX / 16; ++s2) {
-                bf16x8 av[3];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) av[m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG + 16 * s2);
-                mfma6(acc, av, wf[s2]);
-            }
+            // the epilogue's sixteen activations first (LDS returns in order: they are long there when the products finish), then the A
+            // fragments ONE k step ahead of their six MFMAs -- left to the compiler, a step's reads sat right in front of its first MFMA and
+            // the lone D wave of a SIMD ate an LDS round trip per step (1200 of its 5400 cycles per block)
             float zv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+            bf16x8 av[2][3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG);
+#pragma unroll
+            for (int s2 = 0; s2 < CX / 16; ++s2) {
+                if (s2 + 1 < CX / 16) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG + 16 * (s2 + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma6(acc, av[s2 & 1], wf[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
             auto finish = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;
@@ -397,13 +468,18 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             if (valid >= 32) finish(std::true_type{});
             else finish(std::false_type{});
         }
+        BX_STAMP(2);                                   // the role's products (and the D role's epilogue) are issued
         if constexpr (NSETS == 2) {
-            Pos nx3 = nx2;
-            const bool more3 = more2 && advance(nx3);
-            if (!more3) nx3 = nx2;
-            if (more1) write_lds(buf ^ 1, nxt, A);
-            load_regs(nx3, A);
+#ifdef X3B_NO_SKEW
+            if (W_ROLE || !GRAM) {
+#else
+            if (!GRAM) {
+#endif
+                if (more1) write_lds(buf ^ 1, nxt, A);
+                load_regs(nx3, A);
+            }
             __syncthreads();
+            BX_STAMP(4);                               // barrier passed
             buf ^= 1;
             cur = nxt;
             nxt = nx2;
@@ -431,6 +507,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             step(S0, std::true_type{});
         }
     } else {
+        // (s_setprio 2 for this role -- the critical path of a block -- was A/B'd on one box: +1.5 %, dropped)
         while (live) {
             step(NSETS == 2 ? S1 : S0, std::false_type{});
             if (!live) break;
@@ -438,8 +515,31 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
         }
     }
 
+#ifdef AMPNET_PW_STAMPS
+    if (GRAM && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) g_bx_stamps[threadIdx.x >> 8][0] = (unsigned long long)stamp_n;
+#endif
     // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
-    if (w_role) {
+    if (w_role && GRAM) {
+        // the upper-triangle tiles and their mirror images (see the W role above)
+        float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
+        auto put = [&](const f32x16 &acc, int ta, int tb) {
+            const int cy = 32 * tb + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cx = 32 * ta + (e & 3) + 8 * (e >> 2) + 4 * h;
+                dst[(size_t)cx * CY + cy] = acc[e];
+                if (ta != tb) dst[(size_t)cy * CY + cx] = acc[e];
+            }
+        };
+        if (ww < 2) {
+            put(acc_w[0][0], 2 * ww, 2 * ww);
+            put(acc_w[0][1], 2 * ww, 2 * ww + 1);
+            put(acc_w[1][1], 2 * ww + 1, 2 * ww + 1);
+        } else {
+            put(acc_w[0][0], 0, ww);
+            put(acc_w[1][0], 1, ww);
+        }
+    } else if (w_role) {
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
 #pragma unroll
         for (int i = 0; i < TXW; ++i)
@@ -454,7 +554,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             }
     }
     if (a.dbpart) {
-        *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        if (stager) *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
         __syncthreads();
         if (tid < CX) {
             float s = 0.f;
@@ -494,7 +594,9 @@ static int launch_x3(const PwBwd &a, hipStream_t st)
     char name[64];
     snprintf(name, sizeof(name), "pw_bwd<128,128>%s x3", GRAM ? "+gram" : "");
     const double rows = (double)a.rows_hint;
-    ProfScope prof(name, 4.0 * rows * 128 * 128, rows * 4.0 * ((a.g.dy ? 128 : 0) + 128 + (GRAM ? 0 : 128) + 128), st);
+    // algorithmic flops the launch stands for (each executed as six bf16 partial products): the symmetric Gram form multiplies 10 of its 16 tiles
+    const double wflops = GRAM ? 2.0 * rows * 128 * 128 * 10.0 / 16.0 : 2.0 * rows * 128 * 128;
+    ProfScope prof(name, wflops + 2.0 * rows * 128 * 128, rows * 4.0 * ((a.g.dy ? 128 : 0) + 128 + (GRAM ? 0 : 128) + 128), st);
     hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(X3B_THREADS), lds, st, a);
     return check_launch("pw_bwd_x3_kernel");
 }
@@ -516,3 +618,12 @@ int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st)
 }
 
 }  // namespace ampnet
+
+#ifdef AMPNET_PW_STAMPS
+extern "C" int ampnet_debug_bx_stamps(unsigned long long *host_out, int max_entries)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t n = (size_t)(max_entries < 4096 ? max_entries : 4096);
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ampnet::g_bx_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

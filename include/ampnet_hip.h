@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPNET_ABI_VERSION 3
+#define AMPNET_ABI_VERSION 4
 
 enum {
     AMPNET_OK = 0,

@@ -55,9 +55,10 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None, fps_cases=None):
         m = re.match(r"ampnet::pw_bwd_x3_kernel<(true|false)>", sym)
         if m:
             name = "pw_bwd<128,128>" + ("+gram" if m.group(1) == "true" else "") + " x3"
-        m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
+        m = re.match(r"ampnet::pw_bwd_kernel<(\d+), (\d+), (\d+), (true|false), (true|false), (true|false), (true|false)", sym)   # <CX, CY, ROWS, GRAM, YACT, ADD, DROP>
         if m:
-            name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "")
+            name = (f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "") + ("" if m.group(5) == "true" else " lin")
+                    + ("+add" if m.group(6) == "true" else "") + ("+drop" if m.group(7) == "true" else ""))
         m = re.match(r"ampnet::pw_bwd_bf16_kernel<(\d+), (\d+), (\d+), (true|false)", sym)
         if m:
             name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("+gram" if m.group(4) == "true" else "") + " bf16"

@@ -6,7 +6,7 @@ PAT=${2:-pw_gemm_kernel<128, 4, 1, true}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in base new base new; do
-  if [ $v = base ]; then export AMPNET_LIB_PATH=$GRAFT_REPO_ROOT/tools/lib_base.so; else unset AMPNET_LIB_PATH; fi
+  if [ $v = base ]; then export AMPNET_LIB_PATH=$GRAFT_REPO_ROOT/tools/lib_base.so; else if [ -n "$AMPNET_NEW_LIB" ]; then export AMPNET_LIB_PATH=$AMPNET_NEW_LIB; else unset AMPNET_LIB_PATH; fi; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v.$RANDOM -o r -- python3 $GRAFT_REPO_ROOT/tools/prof_step.py 6 ${3:-fp32} > $O/log_$v.txt 2>&1 || { tail -5 $O/log_$v.txt; exit 1; }
 done
 cd $GRAFT_REPO_ROOT

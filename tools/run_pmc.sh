@@ -27,6 +27,12 @@ if [ $WHAT = all ] || [ $WHAT = fp32 ]; then
   pmc_set train $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 || rc=1
   echo "fp32 rc=$rc"
 fi
+if [ $WHAT = all ] || [ $WHAT = x3 ]; then
+  # round 4: the headline mode (f32x3: three-term bf16 split operands on the MFMA-bound layers)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_f32x3 -o r -- $PY $GRAFT_REPO_ROOT/tools/prof_step.py 20 f32x3 > $OUT/step_f32x3.log 2>&1 &&
+  pmc_set train_f32x3 $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 f32x3 || rc=1
+  echo "x3 rc=$rc"
+fi
 if [ $rc = 0 ] && { [ $WHAT = all ] || [ $WHAT = bf16 ]; }; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step_bf16 -o r -- $PY $GRAFT_REPO_ROOT/tools/prof_step.py 20 bf16_store > $OUT/step_bf16.log 2>&1 &&
   pmc_set train_bf16_store $PY $GRAFT_REPO_ROOT/tools/prof_step.py 2 bf16_store || rc=1
@@ -50,6 +56,9 @@ fi
 cd $GRAFT_REPO_ROOT
 [ -d $OUT/train ] && python3 profiles/pmc_counters.py $OUT/train $OUT/pmc_counters.json | tail -18
 [ -d $OUT/train_bf16_store ] && python3 profiles/pmc_counters.py $OUT/train_bf16_store $OUT/pmc_counters_bf16_store.json | tail -12
+[ -d $OUT/train_f32x3 ] && python3 profiles/pmc_counters.py $OUT/train_f32x3 $OUT/pmc_counters_f32x3.json | tail -14
+[ -d $OUT/train_f32x3 ] && python3 profiles/pmc_traffic.py $OUT/train_f32x3 $OUT/pmc_traffic_f32x3.json
+[ -f $OUT/step_f32x3/r_kernel_stats.csv ] && python3 tools/step_stats.py $OUT/step_f32x3/r_kernel_stats.csv 14
 FPSARGS=""
 [ -d $OUT/fps ] && FPSARGS="--fps $OUT/fps"
 for c in stage2_256x8192_to_4096 stage1_16x16384_to_8192 stage1_256x16384_to_8192 stream_8x32768_to_8192; do [ -d $OUT/fps_$c ] && FPSARGS="$FPSARGS --fps-case $c=$OUT/fps_$c"; done

@@ -42,3 +42,21 @@ print("span ticks", span)
 for k, v in tot.items():
     print(f"{k:40s} n={len(v):4d} mean={np.mean(v):10.1f} sum={np.sum(v):10d} share={np.sum(v) / span:.3f}")
 print("first 40 deltas:", [(int(ids[i]), int(dt[i])) for i in range(min(40, n - 1))])
+
+# ---- the split backward (Gram form): wave 0 = W role, wave 4 = D role of workgroup 0
+buf2 = (ctypes.c_ulonglong * 4096)()
+if hasattr(L.lib(), "ampnet_debug_bx_stamps") and L.lib().ampnet_debug_bx_stamps(buf2, 4096) == 0:
+    b = np.frombuffer(buf2, dtype=np.uint64).reshape(2, 2048)
+    nm = {1: "block begin", 2: "products issued", 3: "next block staged", 4: "barrier passed"}
+    for role, name in ((0, "W wave 0"), (1, "D wave 4")):
+        n = int(b[role][0])
+        ids = (b[role][1:1 + n] >> np.uint64(48)).astype(int)
+        ts = (b[role][1:1 + n] & np.uint64(0xffffffffffff)).astype(np.int64)
+        d = np.diff(ts)
+        agg = {}
+        for i in range(n - 1):
+            if 0 < d[i] < 10**7:
+                agg.setdefault(f"{nm.get(ids[i], ids[i])} -> {nm.get(ids[i + 1], ids[i + 1])}", []).append(int(d[i]))
+        print(name, "stamps", n)
+        for k, v in agg.items():
+            print(f"   {k:44s} n={len(v):4d} mean={np.mean(v):9.1f} median={np.median(v):9.1f}")
