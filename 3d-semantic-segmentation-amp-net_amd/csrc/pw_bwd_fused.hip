@@ -305,6 +305,10 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
     const float c_undrop = DROP ? 1.0f - a.prev.drop_p : 1.0f;     // a = a' (1 - p) for a kept element
     const bool do_part = a.part_a != nullptr;
     float s_a = 0.f, s_b = 0.f;
+    // (Round 4, tried and dropped: the phase skew that helps the split kernel pw_bwd_x3.hip -- the W wave stages block n + 1 BEFORE its
+    // products of block n, so that one wave's VALU phase lies under the other's MFMA phase -- made THIS kernel slower in a same-box A/B:
+    // <128,64> 484 -> 536 us, <64,64> 271 -> 288 us, <64,128> +2 % (gpurun_out/r4_ab7): next to the 64-cycle fp32 MFMA a VALU instruction
+    // of the partner wave is not hidden, it only competes.)
     Pos cur, nxt;
     bool live = open_item(item_begin, cur);
     if (live && w_role) load_regs(cur);
