@@ -601,12 +601,416 @@ static int launch_x3(const PwBwd &a, hipStream_t st)
     return check_launch("pw_bwd_x3_kernel");
 }
 
+// ---- 128 x 64 (the four launches behind the feature T-Net / conv_4: dy [R, 128], z [R, 128], z_prev [R, 64] -> out [R, 64]) -------------------
+// The fp32 kernel of this shape was the step's dominant one at 0.57 matrix-pipe busy and 3.9 TB/s (neither roof); in split arithmetic its
+// MFMA time is 3 / 8, which leaves HBM.  Blocks of 32 rows (three images of two staged tiles of 64 rows would not fit LDS) give the data
+// gradient TWO 32 x 32 tiles and the weight gradient eight, so the eight waves take three roles, one MFMA wave and one VALU wave per SIMD:
+//     waves 0, 1, 6, 7 (S): stage -- loads two blocks ahead, g = dy P1 + z P2 + P3 and a = relu(bn(z_prev)) in fp32, the three-term
+//                            split, LDS writes; bias / column sums of g
+//     waves 2, 3       (W): dW[cx][cy] += sum_rows g a, four 32 x 32 tiles each (k = rows, transposed LDS reads): 48 MFMAs per block
+//     waves 4, 5       (D): out[row][32 d ..] = mask (g W), weight column block as 8 x 3 bf16 fragments in registers: 48 MFMAs per block
+// A workgroup's waves are dealt to the SIMDs 0, 1, 2, 3, 0, 1, 2, 3: every SIMD holds one MFMA wave and one staging wave.
+template <bool YACT>
+__global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
+{
+    constexpr int CX = 128, CY = 64, ROWS = 32;
+    constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 rows of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
+    constexpr int LDZ = CY + 4;                     // fp32 row of the (activated) input tile
+    constexpr int IMGG = ROWS * LDG, IMGY = ROWS * LDY;
+    constexpr int NS = 256;                         // staging threads
+    constexpr int QX = CX / 4, QY = CY / 4;         // 32 / 16 channel quads
+    constexpr int SX = NS / QX, SY = NS / QY;       // 8 / 16 row groups
+    constexpr int NIX = ROWS / SX, NIY = ROWS / SY; // 4 / 2 quads per staging thread
+    constexpr size_t BUF = (size_t)3 * IMGG * 2 + (size_t)3 * IMGY * 2 + (size_t)ROWS * LDZ * 4;      // bytes of one staged block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *red = reinterpret_cast<float *>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
+    const bool s_role = wave < 2 || wave >= 6, w_role = wave == 2 || wave == 3, d_role = wave == 4 || wave == 5;
+    const int stid = ((wave < 2 ? wave : wave - 4) << 6) | lane;       // 0 .. 255 over the four staging waves
+    const int cqx = stid % QX, rsx = stid / QX, cqy = stid % QY, rsy = stid / QY;
+
+    const int per_slot = (a.Q - slot + a.n_slots - 1) / a.n_slots;
+    const int cpw = (a.max_rows + X3B_ITEM_ROWS - 1) / X3B_ITEM_ROWS;
+    const int n_items = per_slot * cpw;
+    const int ipb = a.items_per_block > 0 ? a.items_per_block : (n_items + a.blocks_per_slot - 1) / a.blocks_per_slot;
+    const int item_begin = min(jb * ipb, n_items), item_end = min(item_begin + ipb, n_items);
+
+    // ---- BatchNorm-backward constants of the layer g belongs to (formed here from the producer's partial sums, or read) ----
+    f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
+    if (a.fin_part_a) {
+        // every thread takes part (512 = 16 groups of 32 channel quads), pw_bwd_fused.hip: fin_*
+        const int fq = tid % QX, fg = tid / QX;
+        double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+        const int per_slot_parts = (a.fin_parts - slot + a.n_slots - 1) / a.n_slots;
+        for (int k0 = fg; k0 < per_slot_parts; k0 += 16 * 8) {
+            f32x4 va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                const size_t o = (size_t)(slot + (k < per_slot_parts ? k : 0) * a.n_slots) * CX + 4 * fq;
+                va[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_a + o);
+                vb[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_b + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (k0 + 16 * u < per_slot_parts) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sa[c] += (double)va[u][c];
+                        sb[c] += (double)vb[u][c];
+                    }
+                }
+            }
+        }
+        double *redd = reinterpret_cast<double *>(smem_raw);          // [16][CX][2] = 32 KB: the staging buffers are not in use yet
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            redd[((size_t)fg * CX + 4 * fq + c) * 2 + 0] = sa[c];
+            redd[((size_t)fg * CX + 4 * fq + c) * 2 + 1] = sb[c];
+        }
+        __syncthreads();
+        const double n = (double)a.fin_rows;
+        f32x4 q1, q2, q3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * cqx + c;
+            double A = 0.0, Bs = 0.0;
+            for (int gq = 0; gq < 16; ++gq) {
+                A += redd[((size_t)gq * CX + ch) * 2 + 0];
+                Bs += redd[((size_t)gq * CX + ch) * 2 + 1];
+            }
+            const size_t o = (size_t)slot * CX + ch;
+            const double invstd = a.fin_invstd[o], mean = a.fin_mean[o];
+            const double sc = (double)a.fin_gamma[ch] * invstd;
+            const double qq = -sc * invstd * Bs / n;
+            q1[c] = (float)sc;
+            q2[c] = (float)qq;
+            q3[c] = (float)(-sc * A / n - qq * mean);
+            if (jb == 0 && tid < QX) {                          // one writer per slot (threads 0 .. 31 = wave 0: cqx = tid)
+                a.fin_slot_ab[o * 2 + 0] = (float)A;
+                a.fin_slot_ab[o * 2 + 1] = (float)Bs;
+            }
+        }
+        p1 = q1; p2 = q2; p3 = q3;
+        if (jb == 0 && tid < QX) {
+            *reinterpret_cast<f32x4 *>(a.fin_P1 + (size_t)slot * CX + 4 * cqx) = p1;
+            *reinterpret_cast<f32x4 *>(a.fin_P2 + (size_t)slot * CX + 4 * cqx) = p2;
+            *reinterpret_cast<f32x4 *>(a.fin_P3 + (size_t)slot * CX + 4 * cqx) = p3;
+        }
+        __syncthreads();
+    } else {
+        p1 = *reinterpret_cast<const f32x4 *>(a.g.P1 + (size_t)slot * CX + 4 * cqx);
+        p2 = *reinterpret_cast<const f32x4 *>(a.g.P2 + (size_t)slot * CX + 4 * cqx);
+        p3 = *reinterpret_cast<const f32x4 *>(a.g.P3 + (size_t)slot * CX + 4 * cqx);
+    }
+    f32x4 ys = {1.f, 1.f, 1.f, 1.f}, yt = {0.f, 0.f, 0.f, 0.f};
+    if (YACT) {
+        ys = *reinterpret_cast<const f32x4 *>(a.prev.s + (size_t)slot * CY + 4 * cqy);
+        yt = *reinterpret_cast<const f32x4 *>(a.prev.t + (size_t)slot * CY + 4 * cqy);
+    }
+
+    struct Pos {
+        int item, row0, row_end;
+    };
+    auto open_item = [&](int item, Pos &p) -> bool {
+        for (; item < item_end; ++item) {
+            const int q = (item / cpw) * a.n_slots + slot, ch = item % cpw;
+            const int rb = a.win_off[q] + ch * X3B_ITEM_ROWS;
+            const int re = min(a.win_off[q + 1], rb + X3B_ITEM_ROWS);
+            if (rb < re) {
+                p.item = item;
+                p.row0 = rb;
+                p.row_end = re;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto advance = [&](Pos &p) -> bool {
+        if (p.row0 + ROWS < p.row_end) {
+            p.row0 += ROWS;
+            return true;
+        }
+        return open_item(p.item + 1, p);
+    };
+
+    struct Regs {
+        f32x4 dy[NIX], xz[NIX], yz[NIY];
+    };
+    auto load_regs = [&](const Pos &p, Regs &R) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int row = p.row0 + rsx + SX * i;
+            const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
+            R.xz[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int row = p.row0 + rsy + SY * i;
+            const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
+            R.yz[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
+        }
+    };
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    const bool want_db = a.dbpart != nullptr;
+    auto write_lds = [&](int buf_, const Pos &p, const Regs &R) {
+        int bsel = buf_;
+        asm volatile("" : "+s"(bsel));               // keeps the addresses of the two buffers from being hoisted apart (see pw_bwd_x3_kernel)
+        __bf16 *g = reinterpret_cast<__bf16 *>(smem_raw + bsel * BUF);
+        __bf16 *y = g + 3 * IMGG;
+        float *z = reinterpret_cast<float *>(y + 3 * IMGY);
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int lrow = rsx + SX * i, row = p.row0 + lrow;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (row < p.row_end) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xv[c] = fmaf(R.dy[i][c], p1[c], fmaf(R.xz[i][c], p2[c], p3[c]));
+                if (want_db) dbacc += xv;
+            }
+            bf16x4 t1, t2, t3;
+            split4(xv, t1, t2, t3);
+            *reinterpret_cast<bf16x4 *>(g + lrow * LDG + 4 * cqx) = t1;
+            *reinterpret_cast<bf16x4 *>(g + IMGG + lrow * LDG + 4 * cqx) = t2;
+            *reinterpret_cast<bf16x4 *>(g + 2 * IMGG + lrow * LDG + 4 * cqx) = t3;
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int lrow = rsy + SY * i, row = p.row0 + lrow;
+            f32x4 yv = R.yz[i];
+            if (YACT) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yv[c] = fmaxf(fmaf(yv[c], ys[c], yt[c]), 0.f);
+                *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqy) = yv;           // (finite filler on rows past the end: masked in the epilogue)
+            }
+            if (!(row < p.row_end)) yv = f32x4{0.f, 0.f, 0.f, 0.f};               // rows past the block's end contribute nothing to dW
+            bf16x4 t1, t2, t3;
+            split4(yv, t1, t2, t3);
+            *reinterpret_cast<bf16x4 *>(y + lrow * LDY + 4 * cqy) = t1;
+            *reinterpret_cast<bf16x4 *>(y + IMGY + lrow * LDY + 4 * cqy) = t2;
+            *reinterpret_cast<bf16x4 *>(y + 2 * IMGY + lrow * LDY + 4 * cqy) = t3;
+        }
+    };
+
+    // ---- role state ----
+    const int wi = wave & 1;                               // W: column blocks 2 wi, 2 wi + 1 of cx;  D: column block wi of cy
+    f32x16 acc_w[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_w[i][j][e] = 0.f;
+    const int dcol = 32 * wi + r;
+    bf16x8 wf[CX / 16][3];
+    if (d_role) {
+        const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+#pragma unroll
+        for (int s2 = 0; s2 < CX / 16; ++s2) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol];
+            split8(v, wf[s2][0], wf[s2][1], wf[s2][2]);
+        }
+    }
+    const float c_b = a.bias_slot ? a.bias_slot[(size_t)slot * CY + dcol] : 0.f;
+    const float c_s = YACT ? a.prev.s[(size_t)slot * CY + dcol] : 1.0f;
+    const float c_t = YACT ? a.prev.t[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_m = (YACT && a.prev_mean) ? a.prev_mean[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_i = (YACT && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
+    const float c_beta = fmaf(c_m, c_s, c_t);
+    const float c_invg = c_s != 0.f ? c_i / c_s : 0.f;
+    const bool do_part = a.part_a != nullptr;
+    float s_a = 0.f, s_b = 0.f;
+
+    // blocks n (in LDS), n + 1 and n + 2 (in the stagers' two register sets); a tail position repeats the last real one (unconditional loads)
+    Pos cur, nxt, nx2;
+    bool live = open_item(item_begin, cur);
+    bool more1 = false, more2 = false;
+    nxt = cur;
+    if (live) more1 = advance(nxt);
+    if (!more1) nxt = cur;
+    nx2 = nxt;
+    if (more1) more2 = advance(nx2);
+    if (!more2) nx2 = nxt;
+    Regs S0, S1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every constant has landed before the loop
+    if (live && s_role) {
+        load_regs(cur, S0);
+        load_regs(nxt, S1);
+        write_lds(0, cur, S0);
+        load_regs(nx2, S0);
+    }
+    __syncthreads();
+    int buf = 0;
+    auto step = [&](Regs &A, auto role_tag) {
+        constexpr int ROLE = decltype(role_tag)::value;          // 0 stage, 1 weight gradient, 2 data gradient
+        int bsel = buf;
+        asm volatile("" : "+s"(bsel));
+        const __bf16 *g = reinterpret_cast<const __bf16 *>(smem_raw + bsel * BUF);
+        const __bf16 *y = g + 3 * IMGG;
+        const float *z = reinterpret_cast<const float *>(y + 3 * IMGY);
+        Pos nx3 = nx2;
+        const bool more3 = more2 && advance(nx3);
+        if (!more3) nx3 = nx2;
+        if constexpr (ROLE == 0) {
+            if (more1) write_lds(buf ^ 1, nxt, A);
+            load_regs(nx3, A);
+        } else if constexpr (ROLE == 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < ROWS / 16; ++s2) {
+                bf16x8 xa[2][3], yb[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand(g + m * IMGG, LDG, 16 * s2, 32 * (2 * wi + i), lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) yb[j][m] = tr_operand(y + m * IMGY, LDY, 16 * s2, 32 * j, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mfma6(acc_w[i][j], xa[i], yb[j]);
+            }
+        } else {
+            const int valid = min(ROWS, cur.row_end - cur.row0);
+            const int trow0 = cur.row0;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = c_b;
+            float zv[16];
+            if (YACT) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+            }
+            const __bf16 *ga = g + r * LDG + 8 * h;
+            bf16x8 av[2][3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMGG);
+#pragma unroll
+            for (int s2 = 0; s2 < CX / 16; ++s2) {
+                if (s2 + 1 < CX / 16) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMGG + 16 * (s2 + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma6(acc, av[s2 & 1], wf[s2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
+            auto finish = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = FULL || rr < valid;
+                    float v = acc[e];
+                    if (YACT) {
+                        v = zv[e] > 0.f ? v : 0.f;                           // ReLU mask of the layer's input: a > 0
+                        const float vs = ok ? v : 0.f;
+                        s_a += vs;
+                        s_b = fmaf(vs, (zv[e] - c_beta) * c_invg, s_b);      // zhat = (a - beta) / gamma where the mask holds
+                    }
+                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                }
+            };
+            if (valid >= 32) finish(std::true_type{});
+            else finish(std::false_type{});
+        }
+        __syncthreads();
+        buf ^= 1;
+        cur = nxt;
+        nxt = nx2;
+        nx2 = nx3;
+        live = more1;
+        more1 = more2;
+        more2 = more3;
+    };
+    if (s_role) {
+        while (live) {
+            step(S1, std::integral_constant<int, 0>{});
+            if (!live) break;
+            step(S0, std::integral_constant<int, 0>{});
+        }
+    } else if (w_role) {
+        while (live) step(S0, std::integral_constant<int, 1>{});
+    } else {
+        while (live) step(S0, std::integral_constant<int, 2>{});
+    }
+
+    // ---- flush ----
+    if (w_role) {
+        float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cy = 32 * j + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int cx = 32 * (2 * wi + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    dst[(size_t)cx * CY + cy] = acc_w[i][j][e];
+                }
+            }
+    }
+    if (a.dbpart) {
+        if (s_role) *reinterpret_cast<f32x4 *>(red + rsx * CX + 4 * cqx) = dbacc;
+        __syncthreads();
+        if (tid < CX) {
+            float sum = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < SX; ++gi) sum += red[gi * CX + tid];
+            a.dbpart[(size_t)blockIdx.x * CX + tid] = sum;
+        }
+        __syncthreads();
+    }
+    if (do_part) {
+        const float oa = __shfl_xor(s_a, 32), ob = __shfl_xor(s_b, 32);
+        if (d_role && h == 0) {
+            red[dcol * 2 + 0] = s_a + oa;
+            red[dcol * 2 + 1] = s_b + ob;
+        }
+        __syncthreads();
+        if (tid < CY) {
+            a.part_a[(size_t)blockIdx.x * CY + tid] = red[tid * 2 + 0];
+            a.part_b[(size_t)blockIdx.x * CY + tid] = red[tid * 2 + 1];
+        }
+    }
+}
+
+template <bool YACT>
+static int launch_x3n(const PwBwd &a, hipStream_t st)
+{
+    constexpr size_t buf = (size_t)3 * 32 * 160 * 2 + (size_t)3 * 32 * 96 * 2 + (size_t)32 * 68 * 4;
+    constexpr size_t lds = 2 * buf;
+    static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
+    static bool attr_set = false;
+    auto kern = pw_bwd_x3n_kernel<YACT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_x3n: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    char name[64];
+    snprintf(name, sizeof(name), "pw_bwd<128,64>%s x3", YACT ? "" : " lin");
+    const double rows = (double)a.rows_hint;
+    ProfScope prof(name, 4.0 * rows * 128 * 64, rows * 4.0 * (128 + 128 + 64 + 64), st);
+    hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(X3B_THREADS), lds, st, a);
+    return check_launch("pw_bwd_x3n_kernel");
+}
+
 // the shapes the split backward is built for; pw_bwd_fused() asks before it dispatches here
 bool pw_bwd_x3_supported(const PwBwd &a)
 {
     const bool gram = a.g.act != 0;
-    return a.g.C == 128 && a.prev.C == 128 && a.prev.s != nullptr && !a.add && !(a.prev.drop_p > 0.f) && !a.w_win_stride && !a.g.z_bf16 && !a.prev.z_bf16 &&
-           (gram ? a.g.z == a.prev.z : (a.g.dy != nullptr));
+    if (a.add || a.prev.drop_p > 0.f || a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
+    if (a.g.C == 128 && a.prev.C == 128) return a.prev.s != nullptr && (gram ? a.g.z == a.prev.z : (a.g.dy != nullptr));
+    if (a.g.C == 128 && a.prev.C == 64) return !gram && a.g.dy != nullptr && a.g.z != nullptr && (a.g.P1 != nullptr || a.fin_part_a != nullptr);
+    return false;
 }
 
 // same argument contract as pw_bwd_fused (it validates before dispatching here)
@@ -614,6 +1018,7 @@ int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st)
 {
     static_assert(X3B_ITEM_ROWS == 256, "item size shared with pw_bwd_fused.hip");
     AMPNET_REQUIRE(pw_bwd_x3_supported(a), "pw_bwd_x3: shape not built");
+    if (a.prev.C == 64) return a.prev.s ? launch_x3n<true>(a, st) : launch_x3n<false>(a, st);
     return a.g.act ? launch_x3<true>(a, st) : launch_x3<false>(a, st);
 }
 
