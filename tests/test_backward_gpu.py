@@ -36,14 +36,17 @@ def _check_grads(got, want64, want32, what):
         if ref >= 1e-3 * gtot:
             rel_floor = max(rel_floor, float((want32[k].double() - w).norm()) / ref)
     bad = []
+    worst = (0.0, "")
     for k, w in want64.items():
         g = got[k].detach().cpu().double().reshape(w.shape)
         err = float((g - w).norm())
         ref = float(w.norm())
         noise = float((want32[k].double() - w).norm())
         tol = max(4.0 * noise, 1.5 * rel_floor * ref) + 2e-3 * ref + 1e-5 * gtot
+        worst = max(worst, (err / tol, k))
         if not err <= tol:
             bad.append((k, err, noise, ref))
+    print(f"[{what}] worst err / tol = {worst[0]:.3f} ({worst[1]}), torch-fp32 relative noise {rel_floor:.2e}")      # shown with -s
     assert not bad, f"{what} (worst torch-fp32 relative noise {rel_floor:.2e}): " + "; ".join(f"{k}: err {e:.3e} fp32-noise {n:.3e} |g| {r:.3e}" for k, e, n, r in bad[:8])
 
 
