@@ -57,3 +57,79 @@ def load_tensor_list(path, allow_pickle=None):
                 return pickle.load(f)
         raise AmpnetError(f"{path}: torch.load(weights_only=True) refused the file ({e}). Re-save the clusters with torch.save(list_of_tensors, path), "
                           "or opt in to full unpickling of a file you produced yourself with allow_pickle=True / AMPNET_ALLOW_PICKLE=1.") from e
+
+
+# ---- torch.save'd single tensors (the kmeans_<name>.pt training samples) -----------------------------------------------------------------
+# torch.load(weights_only=True) runs a pure-Python unpickler: 0.6 ms per 460 KB sample, a third of what a DataLoader worker spends on it.
+# A single saved tensor needs three globals; the C unpickler restricted to exactly those (nothing from the file is imported or called:
+# the storage class becomes a dtype name, the rebuild function a tuple) + one read of the storage record is 10x cheaper and as safe.
+_PT_STORAGE_DTYPES = {"FloatStorage": "float32", "DoubleStorage": "float64", "LongStorage": "int64", "IntStorage": "int32",
+                      "ShortStorage": "int16", "ByteStorage": "uint8", "CharStorage": "int8"}
+
+
+def _pt_rebuild_tensor(storage, storage_offset, size, stride, *unused):
+    return ("tensor", storage, int(storage_offset), tuple(int(v) for v in size), tuple(int(v) for v in stride))
+
+
+class _SingleTensorUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == "torch._utils" and name == "_rebuild_tensor_v2":
+            return _pt_rebuild_tensor
+        if module == "torch" and name in _PT_STORAGE_DTYPES:
+            return _PT_STORAGE_DTYPES[name]
+        if module == "collections" and name == "OrderedDict":
+            import collections
+            return collections.OrderedDict
+        raise pickle.UnpicklingError(f"global {module}.{name} is not part of a plain saved tensor")
+
+    def persistent_load(self, pid):
+        if not (isinstance(pid, tuple) and len(pid) >= 5 and pid[0] == "storage" and isinstance(pid[1], str)):
+            raise pickle.UnpicklingError("unexpected persistent id")
+        return ("storage", pid[1], str(pid[2]), int(pid[4]))          # dtype name, record key, element count
+
+
+def pt_tensor_header(path):
+    """(numpy dtype name, shape, byte offset of the first element in the file) of a torch.save'd single contiguous tensor; raises
+    pickle.UnpicklingError for anything else.  Nothing from the file is executed and the data is not read."""
+    import io
+    reader = torch._C.PyTorchFileReader(path)
+    desc = _SingleTensorUnpickler(io.BytesIO(reader.get_record("data.pkl"))).load()
+    if not (isinstance(desc, tuple) and len(desc) == 5 and desc[0] == "tensor"):
+        raise pickle.UnpicklingError("not a single tensor")
+    _, (_, dtype, key, numel), off, size, stride = desc
+    want, acc = [], 1
+    for d in reversed(size):
+        want.append(acc)
+        acc *= d
+    if tuple(reversed(want)) != stride and acc > 0:
+        raise pickle.UnpicklingError("not contiguous")
+    if off < 0 or off + acc > numel:
+        raise pickle.UnpicklingError("view outside its storage")
+    if reader.has_record("byteorder") and reader.get_record("byteorder") != b"little":
+        raise pickle.UnpicklingError("big-endian file")
+    itemsize = {"float32": 4, "float64": 8, "int64": 8, "int32": 4, "int16": 2, "uint8": 1, "int8": 1}[dtype]
+    return dtype, size, reader.get_record_offset("data/" + key) + off * itemsize
+
+
+def _load_pt_array_fast(path):
+    import numpy as np
+    dtype, size, start = pt_tensor_header(path)
+    count = 1
+    for d in size:
+        count *= d
+    return np.fromfile(path, dtype=np.dtype(dtype), count=count, offset=start).reshape(size)
+
+
+def load_pt_array(path):
+    """A torch.save'd tensor as a numpy array (read once; nothing from the file is executed).  Anything the fast reader does not
+    recognise -- legacy non-zip files, several objects, non-contiguous views -- goes through torch.load(weights_only=True)."""
+    import numpy as np
+    try:
+        return _load_pt_array_fast(path)
+    except Exception:                                    # noqa: BLE001 -- any surprise means "take the general loader"
+        pass
+    try:                                                 # the file mapped, not read: the rows that survive are copied once by the caller
+        t = torch.load(path, map_location=torch.device("cpu"), weights_only=True, mmap=True)
+    except (RuntimeError, ValueError, TypeError):        # legacy (non-zip) torch.save files cannot be mapped
+        t = torch.load(path, map_location=torch.device("cpu"), weights_only=True)
+    return np.asarray(t)

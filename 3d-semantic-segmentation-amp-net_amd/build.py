@@ -35,8 +35,27 @@ def _stamp(src, flags):
     return h.hexdigest()
 
 
+HOST_LIB = os.path.join(HERE, "libampnet_host.so")
+HOST_SRC = [os.path.join(CSRC, "host", "sample_loader.cpp")]
+
+
+def build_host(verbose=True, force=False):
+    """libampnet_host.so (include/ampnet_host.h): the host side of the input pipeline, plain g++ -- no HIP, loadable in DataLoader workers.
+    -ffp-contract=off: its float32 roundings are numpy's."""
+    hdr = os.path.join(HERE, "..", "include", "ampnet_host.h")
+    newest = max(os.path.getmtime(f) for f in HOST_SRC + [hdr])
+    if not force and os.path.exists(HOST_LIB) and os.path.getmtime(HOST_LIB) >= newest:
+        return HOST_LIB
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-o", HOST_LIB] + HOST_SRC
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
+    build_host(verbose, force)
     hipcc = _hipcc()
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     objs, rebuilt = [], False

@@ -126,14 +126,16 @@ def train_att(task, dataset_folder, path_list_files, output_folder, n_points, ba
         train_files = [train_files[i] for i in shard_indices(len(train_files), rank, world)]
         val_files = [val_files[i] for i in shard_indices(len(val_files), rank, world)]
     name = 'ATT' + 'g' + str(GLOBAL_FEAT_SIZE) + 'w100' + 'xyz'
-    train_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=train_files)
-    val_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=val_files)
+    # lazy samples (with the ragged collate): the workers hand collate_seq_ragged file positions and libampnet_host.so reads, filters and
+    # relabels every sample straight into the batch (include/ampnet_host.h) -- a third of the worker time of the numpy statement
+    padded = os.environ.get("AMPNET_PADDED_COLLATE") == "1" or os.environ.get("AMPNET_HOST_AUG") == "1"
+    train_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=train_files, lazy=not padded)
+    val_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=val_files, lazy=not padded)
     # pin_memory: the collated batch (42 MB of points + 9 MB of labels at B = 64) lands in page-locked memory in the loader's pinning
     # thread, so train_loop's single upload runs at PCIe rate instead of through a pageable staging copy (bench.py: train_loop_inclusive)
     # collate: the reference's collate_seq_padd builds the padded [B, 2048, 9, 9] batch in the workers (42 MB of gathers per batch of 64:
     # the epoch then runs at the loader's pace, bench.py train_att_epoch); collate_seq_ragged makes the same draws and leaves resampling
     # and padding to the augmentation kernel.  AMPNET_PADDED_COLLATE=1 (or the numpy augmentation path) selects the reference's.
-    padded = os.environ.get("AMPNET_PADDED_COLLATE") == "1" or os.environ.get("AMPNET_HOST_AUG") == "1"
     mk = lambda ds: torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=number_of_workers,   # noqa: E731
                                                 drop_last=True, collate_fn=collate_seq_padd if padded else collate_seq_ragged, pin_memory=True)
     train_loader, val_loader = mk(train_ds), mk(val_ds)

@@ -4,6 +4,7 @@ random.sample when it has more -- the same calls in the same order, so a seeded 
 clusters are padded to 9 (data and centroids by replicating the last cluster, targets with -1), and the centroids
 come out through the reference's `.view(-1, 9, 2)` reinterpretation of a [B, 2, 1, 9] tensor.
 Runs in DataLoader workers: CPU only, never touches HIP."""
+import os
 import random
 
 import torch
@@ -141,25 +142,65 @@ class RaggedBatch:
         return data, targets
 
 
+def _batch_buffer(numel, dtype):
+    """Uninitialised [numel] tensor; inside a DataLoader worker its storage is shared memory already (torch's default_collate idiom), so
+    handing the batch to the main process does not copy it again."""
+    t = torch.empty(0, dtype=dtype)
+    if torch.utils.data.get_worker_info() is not None:
+        storage = t._typed_storage()._new_shared(numel, device=t.device)
+        return t.new(storage).resize_(numel)
+    return torch.empty(numel, dtype=dtype)
+
+
 def collate_seq_ragged(batch):
     """collate_seq_padd without its 42 MB of host gathers per batch: same arguments, same random draws in the same order (so a seeded
     run resamples identically), but the result carries the samples RAGGED --
         (RaggedBatch, None, filenames, centroids [B, 9, 2] f32)
     and the resampling to 2048 points / padding to 9 clusters happens on the GPU inside the augmentation kernel
-    (amp_step.train_loop -> ampnet_collate_augment_f32).  RaggedBatch.to_padded() rebuilds collate_seq_padd's tensors exactly."""
+    (amp_step.train_loop -> ampnet_collate_augment_f32).  RaggedBatch.to_padded() rebuilds collate_seq_padd's tensors exactly.
+    Samples may arrive unread (datasets.LazyKmeansSample, LidarKmeansDataset(lazy=True)): libampnet_host.so then reads, filters and
+    relabels each file straight into its slice of the batch (include/ampnet_host.h) -- same bytes as the eager samples."""
+    from .. import _hostlib
+    from .datasets import LazyKmeansSample
     B = len(batch)
-    pts, lab, names = [], [], []
+    names = []
     idx = torch.empty((B, N_POINTS), dtype=torch.int32)
     meta = torch.empty((B, 4), dtype=torch.int32)
     cents = torch.empty((B, 2, 1, MAX_WINDOWS), dtype=torch.float32)
+    # upper bounds of the two buffers (a lazy sample may lose rows to the noise filter)
+    tot_p = tot_l = 0
+    eager = []
+    for pc, labels, name, cent in batch:
+        if isinstance(pc, LazyKmeansSample):
+            n, feats, w = pc.n, 9, pc.w
+            eager.append(None)
+        else:
+            pc = torch.as_tensor(pc).float()
+            n, feats, w = pc.shape
+            eager.append(pc)
+        if feats != 9 or w > MAX_WINDOWS:
+            raise ValueError(f"{name}: expected [n, 9, w <= {MAX_WINDOWS}], got [{n}, {feats}, {w}]")
+        tot_p += n * 9 * w
+        tot_l += n * w
+    pts = _batch_buffer(tot_p, torch.float32)
+    lab = _batch_buffer(tot_l, torch.int8)
     po = lo = 0
     ramp = None
+    cbuf = torch.empty((2, 64), dtype=torch.float32)
     for i, (pc, labels, name, cent) in enumerate(batch):
-        pc = torch.as_tensor(pc).float()
-        labels = torch.as_tensor(labels)
-        n, feats, w = pc.shape
-        if feats != 9 or w > MAX_WINDOWS:
-            raise ValueError(f"{name}: expected [n, 9, w <= {MAX_WINDOWS}], got {tuple(pc.shape)}")
+        if eager[i] is None:
+            w = pc.w
+            cb = cbuf[:, :w].contiguous() if pc.want_centroids else None
+            n = _hostlib.lib().ampnet_host_kmeans_file_ragged_f32(os.fsencode(pc.path), pc.offset, pc.n, pc.feats, w, pts.data_ptr() + 4 * po,
+                                                                  lab.data_ptr() + lo, cb.data_ptr() if cb is not None else None)
+            if n < 0:
+                raise RuntimeError(f"{name}: ampnet_host_kmeans_file_ragged_f32 failed ({n})")
+            cent = cb
+        else:
+            pc = eager[i]
+            n, _, w = pc.shape
+            pts[po:po + n * 9 * w] = pc.reshape(-1)
+            lab[lo:lo + n * w] = torch.as_tensor(labels).reshape(-1).to(torch.int8)
         if n < N_POINTS:
             idx[i] = torch.randint(0, n, (N_POINTS,)).to(torch.int32)
         elif n > N_POINTS:
@@ -168,11 +209,9 @@ def collate_seq_ragged(batch):
             if ramp is None:
                 ramp = torch.arange(N_POINTS, dtype=torch.int32)
             idx[i] = ramp
-        pts.append(pc.reshape(-1))
-        lab.append(labels.reshape(-1).to(torch.int8))
         meta[i, 0], meta[i, 1], meta[i, 2], meta[i, 3] = n, w, po, lo
         po += n * 9 * w
         lo += n * w
         _fill_padded(cents, i, torch.as_tensor(cent).float().unsqueeze(1), MAX_WINDOWS, "replicate")
         names.append(name)
-    return RaggedBatch(torch.cat(pts), torch.cat(lab), idx, meta), None, names, cents.view(-1, MAX_WINDOWS, 2)
+    return RaggedBatch(pts[:po], lab[:lo], idx, meta), None, names, cents.view(-1, MAX_WINDOWS, 2)

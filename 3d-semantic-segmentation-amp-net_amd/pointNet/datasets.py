@@ -10,7 +10,8 @@ import numpy as np
 import torch
 from torch.utils import data
 
-from .._safe_load import load_numpy_pickle
+from .. import _hostlib
+from .._safe_load import load_numpy_pickle, load_pt_array, pt_tensor_header
 
 NOISE_CLASSES = (30, 7, 2, 8, 13, 14)     # datasets.py:339-350, deleted in this order
 
@@ -37,12 +38,25 @@ _LABEL_LUT = torch.zeros(256, dtype=torch.long)
 _LABEL_LUT[15], _LABEL_LUT[14], _LABEL_LUT[3], _LABEL_LUT[4], _LABEL_LUT[5] = 1, 2, 3, 3, 4
 
 
+class LazyKmeansSample:
+    """A kmeans_<name>.pt sample that has not been read yet: where its [n, feats, w] float32 record sits in the file.
+    LidarKmeansDataset(lazy=True) hands these to collate_fns.collate_seq_ragged, which has libampnet_host.so read, filter and relabel
+    each one straight into its slice of the batch (one pass, no per-sample arrays)."""
+    __slots__ = ("path", "n", "feats", "w", "offset", "want_centroids")
+
+    def __init__(self, path, n, feats, w, offset, want_centroids):
+        self.path, self.n, self.feats, self.w, self.offset, self.want_centroids = path, n, feats, w, offset, want_centroids
+
+
 class LidarKmeansDataset(data.Dataset):
     NUM_CLASSIFICATION_CLASSES = 2
     POINT_DIMENSION = 2
 
     def __init__(self, dataset_folder, task='classification', number_of_points=None, files=None, fixed_num_points=True,
-                 c_sample=False, sort_kmeans=False, get_centroids=True):
+                 c_sample=False, sort_kmeans=False, get_centroids=True, lazy=False):
+        # lazy (not in the reference): __getitem__ returns (LazyKmeansSample, None, filename, None) for collate_seq_ragged to fill in;
+        # samples the host library cannot take (not float32 [n, >= 10, 2 .. 64], library not built) come back eagerly as usual
+        self.lazy = lazy
         self.dataset_folder = dataset_folder
         self.task = task
         self.n_points = number_of_points
@@ -60,11 +74,30 @@ class LidarKmeansDataset(data.Dataset):
         """-> (pc [n', 9, w] float32 ndarray, labels [n', w] LongTensor, filename, centroids [2, w] ndarray)
         for task == 'segmentation' (the AMP-Net path)."""
         filename = self.paths_files[index]
-        try:                                  # the file mapped, not read: the rows that survive are copied once, below
-            pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True, mmap=True)
-        except (RuntimeError, ValueError, TypeError):       # legacy (non-zip) torch.save files cannot be mapped
-            pc = torch.load(filename, map_location=torch.device('cpu'), weights_only=True)
-        pc = np.asarray(pc)
+        if self.task != 'segmentation':
+            raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
+        host = _hostlib.lib()
+        if self.lazy and host is not None:
+            try:
+                dtype, size, offset = pt_tensor_header(filename)
+                if dtype == "float32" and len(size) == 3 and size[1] >= 10 and 2 <= size[2] <= 64:
+                    return LazyKmeansSample(filename, size[0], size[1], size[2], offset, self.get_centroids), None, filename, None
+            except Exception:                        # noqa: BLE001 -- not a plain saved tensor: the general loader below decides
+                pass
+        pc = load_pt_array(filename)
+        if host is not None and pc.dtype == np.float32 and pc.ndim == 3 and pc.shape[1] >= 10 and 2 <= pc.shape[2] <= 64:
+            # one pass over the sample in libampnet_host.so (include/ampnet_host.h): the same values as the numpy statement below
+            # (w == 1 stays there: numpy sums a length-n column pairwise, a [n, w >= 2] view row by row)
+            pc = np.ascontiguousarray(pc)
+            n, feats, w = pc.shape
+            out = np.empty((n, 9, w), dtype=np.float32)
+            labels = torch.empty((n, w), dtype=torch.int64)
+            cent = np.empty((2, w), dtype=np.float32) if self.get_centroids else None
+            kept = host.ampnet_host_kmeans_sample_f32(pc.ctypes.data, n, feats, w, out.ctypes.data, labels.data_ptr(),
+                                                      cent.ctypes.data if cent is not None else None)
+            if kept < 0:
+                raise RuntimeError(f"{filename}: ampnet_host_kmeans_sample_f32 refused shape {pc.shape}")
+            return out[:kept], labels[:kept], filename, cent
         # a point ROW is dropped from every cluster as soon as one cluster carries a noise code in it
         # (np.delete on axis 0 with the row indices of np.where over [n, w]; datasets.py:339-350)
         # (the reference deletes code by code; the rows that survive all six passes are the rows that carry none of the codes in any
@@ -81,8 +114,6 @@ class LidarKmeansDataset(data.Dataset):
         xy *= 2                                # x, y <- 2 v - 1 in place (the same two float32 roundings as v * 2 - 1)
         xy -= 1
         centroids = np.stack([pc[:, 0, :].mean(0), pc[:, 1, :].mean(0)], axis=0) if self.get_centroids else None
-        if self.task != 'segmentation':
-            raise NotImplementedError("only the segmentation task is on the AMP-Net hot path")
         return pc, labels, filename, centroids
 
 

@@ -11,10 +11,24 @@ record_stream), and the loader's pinned host buffers are released as soon as the
 import torch
 
 
+_COPY_STREAMS = {}
+
+
+def copy_stream(device):
+    """ONE copy stream per device for the life of the process.  torch's caching allocator keeps a pool per stream: with a new stream per
+    epoch the ~30 upload blocks of an epoch (20 MB each) could never be reused by the next one -- 0.6 GB of new hipMalloc calls per epoch,
+    seconds of stall each time and memory that only grows (bench.py train_att_epoch: device_allocator)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device)
+    return _COPY_STREAMS[key]
+
+
 class DevicePrefetcher:
     def __init__(self, loader, device, depth=1):
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
-        self.stream = torch.cuda.Stream(self.device)
+        self.stream = copy_stream(self.device)
 
     def __len__(self):
         return len(self.loader)

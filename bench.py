@@ -484,7 +484,9 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
             names.append(dst)
         ce = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 2, 2, 1, 1]).to(dev), reduction="mean", ignore_index=-1)
         opt_p, opt_a = trainer_mod.FusedAdam(enc.parameters(), lr=1e-3), trainer_mod.FusedAdam(att.parameters(), lr=1e-3)
-        ds = D.LidarKmeansDataset(paths["data"], task="segmentation", number_of_points=N_POINTS, files=names)
+        ds_eager = D.LidarKmeansDataset(paths["data"], task="segmentation", number_of_points=N_POINTS, files=names)
+        ds_lazy = D.LidarKmeansDataset(paths["data"], task="segmentation", number_of_points=N_POINTS, files=names, lazy=True)      # what train_att builds
+        out["host_loader"] = "libampnet_host.so" if sub("_hostlib").lib() is not None else "numpy (library not built)"
         U = sub("utils.utils")
         cpus = U.host_cpu_budget()                     # affinity capped by the cgroup quota (the GPU box: a 16-CPU share of a 256-thread host)
         out["host_cpus"] = cpus
@@ -498,32 +500,61 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
                 return len(self.loader)
 
             def __iter__(self):
-                for b in self.loader:
+                half = len(self.loader) // 2
+                trace = os.environ.get("AMPNET_BENCH_STALL_TRACE") == "1"       # where is the host when a step takes over a second?
+                if trace:
+                    import faulthandler
+                for i, b in enumerate(self.loader):
+                    if i == half:
+                        torch.cuda.synchronize(dev)          # the host runs ahead of the GPU: drain it once so that the second half is timed exactly
                     self.t.append(time.perf_counter())
+                    if trace:
+                        faulthandler.dump_traceback_later(1.0, exit=False)
                     yield b
+                    if trace:
+                        faulthandler.cancel_dump_traceback_later()
 
         # ragged = the package's loader (collate_seq_ragged: the reference's random draws, resampling / padding inside the augmentation
         # kernel, 20 MB per batch); padded = the reference's collate_seq_padd in the workers (51 MB per batch), one worker count for comparison
-        for nw, kind in [(w, "ragged") for w in workers] + [(4, "padded")]:
+        # "ragged" is what amp_train.train_att builds: lazy samples, read / filtered / relabelled by libampnet_host.so inside the collate;
+        # "ragged_eager_samples" = the same collate on samples __getitem__ returned as arrays (the reference's Dataset contract)
+        for nw, kind in [(w, "ragged") for w in workers] + [(4, "ragged_eager_samples"), (4, "padded")]:
             if nw > cpus:
                 continue
-            loader = Stamped(torch.utils.data.DataLoader(ds, batch_size=B, shuffle=True, num_workers=nw, drop_last=True,
-                                                         collate_fn=C.collate_seq_ragged if kind == "ragged" else C.collate_seq_padd, pin_memory=True))
+            loader = Stamped(torch.utils.data.DataLoader(ds_lazy if kind == "ragged" else ds_eager, batch_size=B, shuffle=True, num_workers=nw, drop_last=True,
+                                                         collate_fn=C.collate_seq_padd if kind == "padded" else C.collate_seq_ragged, pin_memory=True))
             np.random.seed(0)
             torch.set_num_threads(max(1, min(threads_before, cpus - nw)))      # as train_att does (limit_host_threads): the pool next to nw workers
+            pin_s = []                                   # the loader's pin thread: seconds per RaggedBatch.pin_memory call (first-use page-locking shows here)
+            orig_pin = C.RaggedBatch.pin_memory
+
+            def timed_pin(self, _o=orig_pin, _l=pin_s):
+                t_ = time.perf_counter()
+                r = _o(self)
+                _l.append(time.perf_counter() - t_)
+                return r
+            C.RaggedBatch.pin_memory = timed_pin
             torch.cuda.synchronize(dev)
+            ms0 = torch.cuda.memory_stats(dev)
             t0 = time.perf_counter()
             m = A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 0)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
+            C.RaggedBatch.pin_memory = orig_pin
             n = len(loader.t)
-            # steady state: the second half of the epoch (the first batches were prefetched while the workers started up)
+            # steady state: the second half of the epoch, from a drained GPU at its first batch to a drained GPU after its last (the first half
+            # holds the workers' start-up and the first-use allocations of the loop)
             h = n // 2
             steady = (t1 - loader.t[h]) / (n - h) if n > 1 else float("nan")
-            out[f"workers_{nw}" + ("" if kind == "ragged" else "_padded_collate")] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
+            stamps = [round(loader.t[i] - t0, 3) for i in (0, n // 4, h, (3 * n) // 4)] + [round(t1 - t0, 3)] if n >= 4 else None
+            out[f"workers_{nw}" + {"ragged": "", "padded": "_padded_collate", "ragged_eager_samples": "_eager_samples"}[kind]] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
                                     "points_per_s": round(B * N_WIN * N_POINTS / steady, 1) if n else None,
                                     "step_share_of_wall": round(resident_ms * 1e-3 / steady, 3) if n else None,
-                                    "first_batch_after_s": round(loader.t[0] - t0, 3) if n else None, "train_loss": round(float(m["loss"]), 4)}
+                                    "first_batch_after_s": round(loader.t[0] - t0, 3) if n else None, "handout_s_at_0_25_50_75_100_pct": stamps,
+                                    "handout_gaps_over_50ms": [[i, round(loader.t[i] - loader.t[i - 1], 3)] for i in range(1, n) if loader.t[i] - loader.t[i - 1] > 0.05],
+                                    "device_allocator": {k: torch.cuda.memory_stats(dev).get(k, 0) - ms0.get(k, 0) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")},
+                                    "pin_thread_s": {"first_half": round(sum(pin_s[:h]), 3), "second_half": round(sum(pin_s[h:]), 3), "max_call": round(max(pin_s), 3)} if pin_s else None,
+                                    "train_loss": round(float(m["loss"]), 4)}
     finally:
         shutil.rmtree(root, ignore_errors=True)
         try:

@@ -272,3 +272,112 @@ def test_collate_seq_ragged_is_collate_seq_padd_unpadded(golden, synth):
     # a DataLoader moves it like a tensor batch: pickling (worker -> main), to()
     rb2 = pickle.loads(pickle.dumps(rb))
     assert torch.equal(rb2.pts, rb.pts) and torch.equal(rb2.idx, rb.idx) and len(rb2) == 5
+
+
+# ---- libampnet_host.so: the per-sample host work of the loader (include/ampnet_host.h) ---------------------------------------------------
+def _host_declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ampnet_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ampnet_host_[a-z0-9_]+)\s*\(", text)))
+
+
+def _host_lib(monkeypatch, mode):
+    H = sub("_hostlib")
+    monkeypatch.setenv("AMPNET_HOST_LOADER", mode)
+    monkeypatch.setattr(H, "_tried", False)
+    monkeypatch.setattr(H, "_lib", None)
+    return H
+
+
+def test_host_library_exports_every_declared_symbol(monkeypatch):
+    H = _host_lib(monkeypatch, "native")
+    lib = H.lib()
+    assert lib is not None, "libampnet_host.so is not built: python __graft_entry__.py build"
+    names = _host_declared_symbols()
+    assert len(names) == 3
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ampnet_host.h but not exported"
+    assert lib.ampnet_host_abi_version() == H.ABI_VERSION
+
+
+def _awkward_sample(synth, seed, n, w):
+    """A kmeans file tensor with every kind of class code the label / noise rules distinguish."""
+    raw = synth.kmeans_file_tensor(seed, n, w)
+    rng = np.random.default_rng(seed)
+    odd = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 30, 31, 32, 255, 256, -1, 14.5, 2.0000002, np.nan, np.inf, 1e9], dtype=np.float32)
+    rows = rng.choice(n, size=min(n, 3 * len(odd)), replace=False)
+    for k, r in enumerate(rows):
+        raw[r, 3, rng.integers(0, w)] = odd[k % len(odd)]
+    return raw
+
+
+@pytest.mark.parametrize("n,w", [(96, 3), (700, 9), (2048, 5), (64, 1), (33, 2), (1, 4)])
+def test_host_kmeans_sample_equals_the_numpy_statement(synth, tmp_path, monkeypatch, n, w):
+    """LidarKmeansDataset.__getitem__ through ampnet_host_kmeans_sample_f32 = the numpy statement of the reference's steps, bit for bit
+    (points, labels, centroids), on class codes of every kind; w == 1 takes the numpy path in both (numpy sums a column pairwise)."""
+    D = sub("pointNet.datasets")
+    raw = _awkward_sample(synth, 500 + n + w, n, w)
+    torch.save(torch.from_numpy(raw), tmp_path / "kmeans_a.pt")
+    got = {}
+    for mode in ("numpy", "native"):
+        H = _host_lib(monkeypatch, mode)
+        assert (H.lib() is not None) == (mode == "native")
+        got[mode] = D.LidarKmeansDataset(str(tmp_path), task="segmentation", number_of_points=2048, files=["a.pt"])[0]
+    a, b = got["numpy"], got["native"]
+    assert a[0].dtype == b[0].dtype == np.float32 and a[1].dtype == b[1].dtype == torch.int64
+    np.testing.assert_array_equal(a[0], b[0])
+    assert torch.equal(a[1], b[1])
+    np.testing.assert_array_equal(a[3], b[3])
+    assert a[3].dtype == b[3].dtype and a[0].shape[0] < n or n == 1 or not np.isin(raw[:, 3, :], D.NOISE_CLASSES).any()
+
+
+def test_load_pt_array_reads_what_torch_load_reads(synth, tmp_path):
+    SL = sub("_safe_load")
+    raw = synth.kmeans_file_tensor(9, 50, 4)
+    t = torch.from_numpy(raw)
+    torch.save(t, tmp_path / "plain.pt")
+    torch.save(t[5:40], tmp_path / "view.pt")                        # a view into a larger storage (storage offset != 0)
+    torch.save(t.transpose(0, 2), tmp_path / "strided.pt")           # not contiguous: the general loader takes it
+    torch.save(t, tmp_path / "legacy.pt", _use_new_zipfile_serialization=False)
+    for name, want in (("plain", t), ("view", t[5:40]), ("strided", t.transpose(0, 2)), ("legacy", t)):
+        got = SL.load_pt_array(str(tmp_path / (name + ".pt")))
+        np.testing.assert_array_equal(np.asarray(got), want.numpy())
+    dtype, size, off = SL.pt_tensor_header(str(tmp_path / "view.pt"))
+    assert dtype == "float32" and size == (35, 13, 4) and off > 0
+    with pytest.raises(Exception):
+        SL.pt_tensor_header(str(tmp_path / "strided.pt"))
+    torch.save({"a": t}, tmp_path / "dict.pt")
+    with pytest.raises(Exception):
+        SL.pt_tensor_header(str(tmp_path / "dict.pt"))
+
+
+def test_lazy_samples_collate_to_the_same_ragged_batch(synth, tmp_path, monkeypatch):
+    """LidarKmeansDataset(lazy=True) + collate_seq_ragged (samples read by ampnet_host_kmeans_file_ragged_f32 straight into the batch) =
+    the eager numpy samples through the same collate: same bytes, same random draws.  The set holds a w == 1 sample and a legacy file (both
+    come back eagerly from the lazy dataset) and samples above and below 2048 surviving rows."""
+    D, C = sub("pointNet.datasets"), sub("pointNet.collate_fns")
+    shapes = [(2500, 5), (2048, 9), (900, 1), (1500, 2), (2300, 7), (2048, 3)]
+    files = []
+    for k, (n, w) in enumerate(shapes):
+        raw = _awkward_sample(synth, 900 + k, n, w) if k != 1 else synth.kmeans_file_tensor(901, n, w, noise_frac=0.0)
+        torch.save(torch.from_numpy(raw), tmp_path / f"kmeans_s{k}.pt", _use_new_zipfile_serialization=(k != 4))
+        files.append(f"s{k}.pt")
+    out = {}
+    for tag, mode, lazy in (("numpy", "numpy", False), ("eager", "native", False), ("lazy", "native", True)):
+        _host_lib(monkeypatch, mode)
+        ds = D.LidarKmeansDataset(str(tmp_path), task="segmentation", number_of_points=2048, files=files, lazy=lazy)
+        items = [ds[i] for i in range(len(files))]
+        if tag == "lazy":
+            kinds = [isinstance(it[0], D.LazyKmeansSample) for it in items]
+            assert kinds == [True, True, False, True, False, True]
+        torch.manual_seed(3)
+        random.seed(3)
+        out[tag] = C.collate_seq_ragged(items)
+    ref = out["numpy"]
+    for tag in ("eager", "lazy"):
+        rb, _, names, cents = out[tag]
+        for k in ("pts", "lab", "idx", "meta"):
+            assert torch.equal(getattr(rb, k), getattr(ref[0], k)), (tag, k)
+        assert names == ref[2] and torch.equal(cents, ref[3])
+    data, targets = out["lazy"][0].to_padded()
+    assert data.shape == (len(files), 2048, 9, 9) and targets.shape == (len(files), 2048, 9)
