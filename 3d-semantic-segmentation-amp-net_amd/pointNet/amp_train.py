@@ -41,6 +41,14 @@ def _dist_setup():
     return 0, 1, 0
 
 
+def start_workers(*loaders):
+    """Fork the worker processes of persistent-worker DataLoaders right away (DataLoader does it at the first iter()); the batches they
+    prefetch meanwhile are dropped when the epoch loop asks for its own iterator.  No-op for loaders without workers."""
+    for ld in loaders:
+        if getattr(ld, "persistent_workers", False) and ld.num_workers > 0 and len(ld) > 0:
+            iter(ld)
+
+
 def _epoch(loader, train, pointnet, att_net, opt_p, opt_a, ce_loss, epoch):
     """One pass over the loader.  Default: predictions and targets never leave the GPU -- per batch one confusion-count kernel and four
     scalars stay queued on the device and are downloaded ONCE at the end of the epoch, so no step synchronises with the host (the
@@ -136,9 +144,15 @@ def train_att(task, dataset_folder, path_list_files, output_folder, n_points, ba
     # collate: the reference's collate_seq_padd builds the padded [B, 2048, 9, 9] batch in the workers (42 MB of gathers per batch of 64:
     # the epoch then runs at the loader's pace, bench.py train_att_epoch); collate_seq_ragged makes the same draws and leaves resampling
     # and padding to the augmentation kernel.  AMPNET_PADDED_COLLATE=1 (or the numpy augmentation path) selects the reference's.
+    # persistent workers, forked NOW: a fork of this process once it holds page-locked memory (the loaders' pinned batches) stalls the GPU
+    # queues for seconds, more each epoch (the kernel write-protects the parent's pages for copy-on-write and the driver revalidates what
+    # it had pinned: 3.6 / 5.3 / 5.9 s at the start of epochs 2 / 3 / 4 with the default per-epoch workers, tools/prof_loader.py) --
+    # so both loaders fork once, before the first pinned allocation, and keep their workers
     mk = lambda ds: torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=number_of_workers,   # noqa: E731
-                                                drop_last=True, collate_fn=collate_seq_padd if padded else collate_seq_ragged, pin_memory=True)
+                                                drop_last=True, collate_fn=collate_seq_padd if padded else collate_seq_ragged, pin_memory=True,
+                                                persistent_workers=number_of_workers > 0)
     train_loader, val_loader = mk(train_ds), mk(val_ds)
+    start_workers(val_loader, train_loader)
     if rank == 0:
         print(f'Dataset folder: {dataset_folder}\nSamples for training: {len(train_ds)} (per rank), validation: {len(val_ds)}')
 

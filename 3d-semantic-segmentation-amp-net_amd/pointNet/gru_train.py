@@ -67,9 +67,13 @@ def train_gru(task, dataset_folder, path_list_files, output_folder, n_points, n_
     name = 'GRU' + str(GLOBAL_FEAT_SIZE) + 'h' + str(HIDDEN_SIZE)
     train_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=train_files, fixed_num_points=c_sample)
     val_ds = LidarKmeansDataset(dataset_folder, task=task, number_of_points=n_points, files=val_files, fixed_num_points=c_sample)
+    # persistent workers, forked before the first pinned batch exists (amp_train.start_workers: a later fork stalls the GPU queues)
     mk = lambda ds: torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=number_of_workers,   # noqa: E731
-                                                drop_last=True, collate_fn=collate_seq_padd, pin_memory=True)
+                                                drop_last=True, collate_fn=collate_seq_padd, pin_memory=True,
+                                                persistent_workers=number_of_workers > 0)
     train_loader, val_loader = mk(train_ds), mk(val_ds)
+    from .amp_train import start_workers
+    start_workers(val_loader, train_loader)
     print(f'Dataset folder: {dataset_folder}\nSamples for training: {len(train_ds)}\nSamples for validation: {len(val_ds)}')
     pointnet = BasePointNet(point_dimension=3, return_local_features=True, global_feat_dim=GLOBAL_FEAT_SIZE, device=device)
     pred_net = SegmentationWithGRU(num_classes=NUM_CLASSES, global_feat_size=GLOBAL_FEAT_SIZE, hidden_size=HIDDEN_SIZE, device=device)

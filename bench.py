@@ -521,8 +521,11 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
         for nw, kind in [(w, "ragged") for w in workers] + [(4, "ragged_eager_samples"), (4, "padded")]:
             if nw > cpus:
                 continue
+            # persistent workers, as train_att builds them; this process already holds page-locked memory, so the fork stalls the GPU queues
+            # for seconds (amp_train.start_workers) -- the warm-up epoch takes that, the timed epoch is the second one
             loader = Stamped(torch.utils.data.DataLoader(ds_lazy if kind == "ragged" else ds_eager, batch_size=B, shuffle=True, num_workers=nw, drop_last=True,
-                                                         collate_fn=C.collate_seq_padd if kind == "padded" else C.collate_seq_ragged, pin_memory=True))
+                                                         collate_fn=C.collate_seq_padd if kind == "padded" else C.collate_seq_ragged, pin_memory=True,
+                                                         persistent_workers=True))
             np.random.seed(0)
             torch.set_num_threads(max(1, min(threads_before, cpus - nw)))      # as train_att does (limit_host_threads): the pool next to nw workers
             pin_s = []                                   # the loader's pin thread: seconds per RaggedBatch.pin_memory call (first-use page-locking shows here)
@@ -535,9 +538,15 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
                 return r
             C.RaggedBatch.pin_memory = timed_pin
             torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 0)             # warm-up epoch: workers fork, first-use allocations
+            torch.cuda.synchronize(dev)
+            warm_s = time.perf_counter() - tw
+            loader.t.clear()
+            pin_s.clear()
             ms0 = torch.cuda.memory_stats(dev)
             t0 = time.perf_counter()
-            m = A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 0)
+            m = A._epoch(loader, True, enc, att, opt_p, opt_a, ce, 1)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             C.RaggedBatch.pin_memory = orig_pin
@@ -546,8 +555,10 @@ def train_att_epoch_leg(enc, att, trainer_mod, B, dev, resident_ms, n_distinct=6
             # holds the workers' start-up and the first-use allocations of the loop)
             h = n // 2
             steady = (t1 - loader.t[h]) / (n - h) if n > 1 else float("nan")
+            whole = (t1 - t0) / n if n else float("nan")             # the timed epoch from a drained GPU to a drained GPU, worker restart included
             stamps = [round(loader.t[i] - t0, 3) for i in (0, n // 4, h, (3 * n) // 4)] + [round(t1 - t0, 3)] if n >= 4 else None
-            out[f"workers_{nw}" + {"ragged": "", "padded": "_padded_collate", "ragged_eager_samples": "_eager_samples"}[kind]] = {"epoch_s": round(t1 - t0, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
+            out[f"workers_{nw}" + {"ragged": "", "padded": "_padded_collate", "ragged_eager_samples": "_eager_samples"}[kind]] = {"epoch_s": round(t1 - t0, 3), "warmup_epoch_s": round(warm_s, 3), "steps": n, "ms_per_step": round(steady * 1e3, 3),
+                                    "ms_per_step_whole_epoch": round(whole * 1e3, 3),
                                     "points_per_s": round(B * N_WIN * N_POINTS / steady, 1) if n else None,
                                     "step_share_of_wall": round(resident_ms * 1e-3 / steady, 3) if n else None,
                                     "first_batch_after_s": round(loader.t[0] - t0, 3) if n else None, "handout_s_at_0_25_50_75_100_pct": stamps,

@@ -32,7 +32,8 @@ try:
     def timed_up(self, batch):
         t0 = time.perf_counter(); r = orig_up(self, batch); tm["upload"].append(time.perf_counter() - t0); return r
     P.DevicePrefetcher._upload = timed_up
-    loader = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=True, num_workers=nw, drop_last=True, collate_fn=C.collate_seq_ragged, pin_memory=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=True, num_workers=nw, drop_last=True, collate_fn=C.collate_seq_ragged, pin_memory=True,
+                                         persistent_workers=os.environ.get('PERSISTENT') == '1')
     class Waited:
         def __len__(self): return len(loader)
         def __iter__(self):
