@@ -5,6 +5,25 @@
 
 namespace ampnet {
 
+// Streaming accesses: the per-row tensors of a layer (hundreds of MB each, read or written once per launch) are loaded and stored with the
+// non-temporal hint, so that they do not push the weights / partials / the other stream's lines out of L2 and the infinity cache on their way
+// through.  Same-box A/B on the 128 -> 64 fused backward: 0.371 -> 0.352 ms (<true>), 0.441 -> 0.398 ms (<false>), step kernel time -0.14 ms.
+// AMPNET_NO_STREAM_HINT at compile time turns them back into plain accesses.
+#if defined(__HIPCC__) || defined(__HIP__)
+#ifdef AMPNET_NO_STREAM_HINT
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) { return *p; }
+template <typename T> __device__ __forceinline__ void st_stream(T v, T *p) { *p = v; }
+#else
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) { return __builtin_nontemporal_load(p); }
+#ifdef AMPNET_NO_STREAM_STORE
+template <typename T> __device__ __forceinline__ void st_stream(T v, T *p) { *p = v; }
+#else
+template <typename T> __device__ __forceinline__ void st_stream(T v, T *p) { __builtin_nontemporal_store(v, p); }
+#endif
+#endif
+#endif
+
+
 // ----------------------------------------------------------------------------------------------------
 // Per-point linear layer ("shared MLP" = Conv1d k=1) on fp32 MFMA:  Z[row, :] = pro(A[row, :]) * W^T + bias
 //   rows are grouped in windows (win_off[q] .. win_off[q+1]); a workgroup owns one chunk of one window and

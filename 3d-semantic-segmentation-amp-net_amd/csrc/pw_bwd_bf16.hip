@@ -160,15 +160,15 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            if (!x_act) R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            R.xz[i] = *reinterpret_cast<const ZGT *>(reinterpret_cast<const std::conditional_t<ZG, __bf16, float> *>(a.g.z) + rr * CX + 4 * cqx);
+            if (!x_act) R.dy[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx));
+            R.xz[i] = ld_stream(reinterpret_cast<const ZGT *>(reinterpret_cast<const std::conditional_t<ZG, __bf16, float> *>(a.g.z) + rr * CX + 4 * cqx));
         }
         if (!GRAM) {
 #pragma unroll
             for (int i = 0; i < NIY; ++i) {
                 const int row = p.row0 + rsy + SY * i;
                 const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-                R.yz[i] = *reinterpret_cast<const ZPT *>(reinterpret_cast<const std::conditional_t<ZP, __bf16, float> *>(a.prev.z) + rr * CY + 4 * cqy);
+                R.yz[i] = ld_stream(reinterpret_cast<const ZPT *>(reinterpret_cast<const std::conditional_t<ZP, __bf16, float> *>(a.prev.z) + rr * CY + 4 * cqy));
             }
         }
     };
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FBB_THREADS, 1) void pw_bwd_bf16_kernel(PwBwd a)
                         s_a += vs;
                         s_b = fmaf(vs, (zv[e] - c_m) * c_i, s_b);
                     }
-                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                    if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
                 }
             };
             if (valid >= 32) finish(std::true_type{});

@@ -211,8 +211,8 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
             const int row = p.row0 + rsx + SX * i;
             size_t rr = (size_t)(row < p.row_end ? row : p.row0);
             if (a.dbg_row_wrap) rr &= (size_t)(a.dbg_row_wrap - 1);       // power of two
-            if (!x_act) rx_dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            if (has_bn || x_act) rx_z[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+            if (!x_act) rx_dy[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx));
+            if (has_bn || x_act) rx_z[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx));
         }
         if (!same) {
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                 const int row = p.row0 + rsy + SY * i;
                 size_t rr = (size_t)(row < p.row_end ? row : p.row0);
                 if (a.dbg_row_wrap) rr &= (size_t)(a.dbg_row_wrap - 1);
-                ry_z[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
+                ry_z[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy));
             }
         }
     };
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    addv[e] = rr < valid ? a.add[(size_t)(trow0 + rr) * CY + dcol] : 0.f;
+                    addv[e] = rr < valid ? ld_stream(&a.add[(size_t)(trow0 + rr) * CY + dcol]) : 0.f;
                 }
             }
             // one accumulator, started at the per-slot bias: dependent fp32 MFMAs issue back to back at full rate (tools/mfma_probe2.hip),
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(FB_THREADS, 1) void pw_bwd_kernel(PwBwd a)
                         s_a += vs;
                         s_b = fmaf(vs, SACT ? (zv[e] * c_undrop - c_beta) * c_invg : (zv[e] - c_m) * c_i, s_b);
                     }
-                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                    if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
                 }
             };
             if (valid >= 32) finish(std::true_type{});

@@ -242,9 +242,9 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            if (!GRAM) R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            R.xz[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
-            if (!GRAM) R.yz[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqx);
+            if (!GRAM) R.dy[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx));
+            R.xz[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx));
+            if (!GRAM) R.yz[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqx));
         }
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
                     const float vs = ok ? v : 0.f;
                     s_a += vs;
                     s_b = fmaf(vs, (zv[e] - c_beta) * c_invg, s_b);          // zhat = (a - beta) / gamma where the mask holds
-                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                    if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
                 }
             };
             if (valid >= 32) finish(std::true_type{});
@@ -744,14 +744,14 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
         for (int i = 0; i < NIX; ++i) {
             const int row = p.row0 + rsx + SX * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            R.dy[i] = *reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx);
-            R.xz[i] = *reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx);
+            R.dy[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.dy + rr * CX + 4 * cqx));
+            R.xz[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.g.z + rr * CX + 4 * cqx));
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
             const int row = p.row0 + rsy + SY * i;
             const size_t rr = (size_t)(row < p.row_end ? row : p.row0);
-            R.yz[i] = *reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy);
+            R.yz[i] = ld_stream(reinterpret_cast<const f32x4 *>(a.prev.z + rr * CY + 4 * cqy));
         }
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
                         s_a += vs;
                         s_b = fmaf(vs, (zv[e] - c_beta) * c_invg, s_b);      // zhat = (a - beta) / gamma where the mask holds
                     }
-                    if (ok) op[((e & 3) + 8 * (e >> 2)) * CY] = v;
+                    if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
                 }
             };
             if (valid >= 32) finish(std::true_type{});

@@ -138,6 +138,12 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
     static_assert(!X3 || (BF && !ABF && !ZBF && !PIPE), "the split kernels are bf16-MFMA kernels on fp32 tensors");
     constexpr int PW_NW = NW;          // (shadows the namespace constant: every use below means this kernel's wave count)
     constexpr int NIMG = X3 ? 3 : 1;   // bf16 images of the weight tile in LDS
+    // (kernels.h: ld_stream / st_stream -- the switch is kept for the A/B)
+    // measured, same box: the FORWARD layers lose 6 .. 20 % with streamed stores (a layer's output is the next layer's input within microseconds and the
+    // infinity cache holds a good part of it) and 5 .. 21 % with streamed loads alone (a lane reads 16 bytes of a row per k step: the eight pieces of a
+    // 128-byte line arrive over eight instructions, and a line marked evict-first does not survive that long) -- the fused backward, whose staging
+    // threads read whole rows per instruction, gains 2 .. 7 % from both (kernels.h)
+    constexpr bool STREAM_LD = false, STREAM = false;
     constexpr int CB = 32 * NT;
     constexpr int LDW = CIN + 4;       // fp32 weight row (floats)
     constexpr int LDB = CIN + 8;       // bf16 weight row (elements): 16-byte aligned rows, conflict-free ds_read_b128
@@ -496,8 +502,13 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
                             if (ok0) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0) * a.ldz + col] = (__bf16)(d0 + z0);
                             if (ok1) reinterpret_cast<__bf16 *>(a.Z)[((size_t)row0 + rr0 + 1) * a.ldz + col] = (__bf16)(d1 + z0);
                         } else {
-                            if (ok0) zp[(size_t)rr0 * a.ldz] = d0 + z0;
-                            if (ok1) zp[(size_t)(rr0 + 1) * a.ldz] = d1 + z0;
+                            if (STREAM) {
+                                if (ok0) st_stream(d0 + z0, &zp[(size_t)rr0 * a.ldz]);
+                                if (ok1) st_stream(d1 + z0, &zp[(size_t)(rr0 + 1) * a.ldz]);
+                            } else {
+                                if (ok0) zp[(size_t)rr0 * a.ldz] = d0 + z0;
+                                if (ok1) zp[(size_t)(rr0 + 1) * a.ldz] = d1 + z0;
+                            }
                         }
                     }
                     if (STATS) {
@@ -548,8 +559,13 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
             // rows past the block's end re-read its last row: their products are never used
             const int row = min(rb_ + st_ * 32 + r, re_ - 1);
             const float *ap = a.A + (size_t)row * a.lda + 16 * step_ + 8 * h;
-            dst[0] = *reinterpret_cast<const f32x4 *>(ap);
-            dst[1] = *reinterpret_cast<const f32x4 *>(ap + 4);
+            if (STREAM_LD) {
+                dst[0] = ld_stream(reinterpret_cast<const f32x4 *>(ap));
+                dst[1] = ld_stream(reinterpret_cast<const f32x4 *>(ap + 4));
+            } else {
+                dst[0] = *reinterpret_cast<const f32x4 *>(ap);
+                dst[1] = *reinterpret_cast<const f32x4 *>(ap + 4);
+            }
         };
         // the wave's first tile of the NEXT block of rows this workgroup walks: its first steps are requested under the last tile of this
         // block, so the pipeline does not drain at the block boundary (reduction + barriers run over loads in flight)
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
         } else {
             const float *ap = frag_ptr(t_, kb_);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
+            for (int j = 0; j < 4; ++j) dst[j] = STREAM_LD ? ld_stream(reinterpret_cast<const f32x4 *>(ap + frag_off(j))) : *reinterpret_cast<const f32x4 *>(ap + frag_off(j));
         }
     };
     int tile = wave;
