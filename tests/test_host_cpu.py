@@ -381,3 +381,30 @@ def test_lazy_samples_collate_to_the_same_ragged_batch(synth, tmp_path, monkeypa
         assert names == ref[2] and torch.equal(cents, ref[3])
     data, targets = out["lazy"][0].to_padded()
     assert data.shape == (len(files), 2048, 9, 9) and targets.shape == (len(files), 2048, 9)
+
+
+def test_start_workers_keeps_every_epoch_complete(synth, tmp_path):
+    """amp_train.start_workers forks the persistent workers before the epoch loop asks for its iterator; the batches prefetched meanwhile are
+    dropped, the epochs that follow are complete (every sample exactly once, len(loader) batches), and the worker processes are the same
+    ones from epoch to epoch (no fork after start-up: DESIGN.md section 5, loader-fed epoch)."""
+    D, C, A = sub("pointNet.datasets"), sub("pointNet.collate_fns"), sub("pointNet.amp_train")
+    files = []
+    for k in range(12):
+        torch.save(torch.from_numpy(synth.kmeans_file_tensor(40 + k, 300 + 7 * k, 2 + k % 3, noise_frac=0.0)), tmp_path / f"kmeans_f{k}.pt")
+        files.append(f"f{k}.pt")
+    ds = D.LidarKmeansDataset(str(tmp_path), task="segmentation", number_of_points=2048, files=files, lazy=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=True, num_workers=2, drop_last=True, collate_fn=C.collate_seq_ragged,
+                                         persistent_workers=True)
+    A.start_workers(loader)
+    pids = None
+    for epoch in range(2):
+        names, nb = [], 0
+        for rb, _, fn, cents in loader:
+            assert len(rb) == 4 and cents.shape == (4, 9, 2)
+            names += fn
+            nb += 1
+        assert nb == len(loader) == 3 and sorted(names) == sorted(ds.paths_files)
+        now = sorted(w.pid for w in loader._iterator._workers)
+        assert pids is None or now == pids
+        pids = now
+    A.start_workers(torch.utils.data.DataLoader(ds, batch_size=4, num_workers=0))       # no workers: nothing to do
