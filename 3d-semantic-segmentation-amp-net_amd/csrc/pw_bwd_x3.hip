@@ -89,6 +89,31 @@ __device__ __forceinline__ bf16x8 tr_operand(const __bf16 *tile, int ld, int row
     return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// ---- the g images are swizzled: the 16-byte granule gi of row `lrow` sits at gi ^ ((lrow >> 2) & 3) ----
+// The row pitch (2 C + 64 bytes) makes the weight-gradient role's transposed reads conflict-free (four rows x 64 bytes per 32 lanes), but rows
+// r, r + 4, r + 8, r + 12 then start in the same bank group, and the data-gradient role's row-major ds_read_b128 (lane = row) replayed four times:
+// SQ_LDS_BANK_CONFLICT was 40 % of SQ_LDS_IDX_ACTIVE in these kernels.  The XOR moves those four rows to four different granules of an aligned
+// group of four; a transposed read touches four rows of ONE such quartet (same XOR for all of them: still four disjoint 64-byte segments), the
+// staging writes permute within a row.  Both readers and the writer below go through these helpers.
+__device__ __forceinline__ int swz_col(int lrow, int c) { return ((((c >> 3) ^ ((lrow >> 2) & 3)) << 3) | (c & 7)); }
+struct TrLane {           // per-lane constants of a swizzled transposed read (rows row0 .. row0 + 15, row0 a multiple of 16; col0 a multiple of 32)
+    int lo, hi;           // element offsets of the lane's two 8-byte pieces relative to tile + row0 * ld + col0
+};
+__device__ __forceinline__ TrLane tr_lane(int ld, int lane)
+{
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = 8 * (g4 >> 1) + q, col = 16 * (g4 & 1) + 4 * p;
+    return TrLane{row * ld + swz_col(row, col), (row + 4) * ld + swz_col(row + 4, col)};
+}
+__device__ __forceinline__ bf16x8 tr_operand_swz(const __bf16 *tile, int ld, int row0, int col0, const TrLane &t)
+{
+    const __bf16 *src = tile + row0 * ld + col0;
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + t.lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + t.hi));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // acc += x * y from the three terms of each: six exact partial products, the small ones first
 __device__ __forceinline__ void mfma6(f32x16 &acc, const bf16x8 (&x)[3], const bf16x8 (&y)[3])
 {
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
 {
     constexpr int CX = 128, CY = 128, ROWS = 32;
     constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 elements per row of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
-    constexpr int LDZ = CY + 4;                     // fp32 row of the activated-input tile
+    constexpr int LDZ = CY + 8;                     // fp32 row of the activated-input tile (4 rows = 32 banks on: the two row groups of a ds_read_b32 do not collide)
     constexpr int TYN = CY / 32;
     constexpr int TXW = 2, TYW = 2;                 // W role: 2 x 2 tiles per wave
     // Gram form: the four W waves stage (their role is the lighter one: no epilogue, no stores), the D waves only multiply, mask and store --
@@ -125,6 +150,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     float *red = reinterpret_cast<float *>(smem_raw);                                    // reductions alias the tiles (before / after the loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const TrLane trl = tr_lane(LDG, lane);
     const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
 
     // ---- work split: items = (window of this slot, chunk of X3B_ITEM_ROWS rows), contiguous share per workgroup ----
@@ -272,9 +298,10 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             }
             bf16x4 t1, t2, t3;
             split4(xv, t1, t2, t3);
-            *reinterpret_cast<bf16x4 *>(g + lrow * LDG + 4 * cqx) = t1;
-            *reinterpret_cast<bf16x4 *>(g + IMG + lrow * LDG + 4 * cqx) = t2;
-            *reinterpret_cast<bf16x4 *>(g + 2 * IMG + lrow * LDG + 4 * cqx) = t3;
+            const int gofs = lrow * LDG + swz_col(lrow, 4 * cqx);
+            *reinterpret_cast<bf16x4 *>(g + gofs) = t1;
+            *reinterpret_cast<bf16x4 *>(g + IMG + gofs) = t2;
+            *reinterpret_cast<bf16x4 *>(g + 2 * IMG + gofs) = t3;
             if (GRAM) {
                 *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqx) = xv;           // the activated input IS g here
             } else {
@@ -389,8 +416,8 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
                     bf16x8 c0[3], c1[3];
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
-                        c0[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww), lane);
-                        c1[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww + 1), lane);
+                        c0[m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww), trl);
+                        c1[m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 32 * (2 * ww + 1), trl);
                     }
                     mfma6(acc_w[0][0], c0, c0);
                     mfma6(acc_w[0][1], c0, c1);
@@ -399,9 +426,9 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
                     bf16x8 c0[3], c1[3], c2[3];
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
-                        c0[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 0, lane);
-                        c1[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32, lane);
-                        c2[m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * ww, lane);
+                        c0[m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 0, trl);
+                        c1[m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 32, trl);
+                        c2[m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 32 * ww, trl);
                     }
                     mfma6(acc_w[0][0], c0, c2);
                     mfma6(acc_w[1][0], c1, c2);
@@ -414,7 +441,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
 #pragma unroll
                 for (int i = 0; i < TXW; ++i)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand(g + m * IMG, LDG, 16 * s2, 32 * (tx0 + i), lane);
+                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand_swz(g + m * IMG, LDG, 16 * s2, 32 * (tx0 + i), trl);
 #pragma unroll
                 for (int j = 0; j < TYW; ++j)
 #pragma unroll
@@ -430,7 +457,8 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = c_b;
-            const __bf16 *ga = g + r * LDG + 8 * h;
+            // the lane's row of g, swizzled (see swz_col): k steps 2 j and 2 j + 1 sit in the granules (2 * 0 + h) ^ x and (2 * 1 + h) ^ x of quartet j
+            const __bf16 *ga2[2] = {g + r * LDG + 8 * ((0 + h) ^ ((r >> 2) & 3)), g + r * LDG + 8 * ((2 + h) ^ ((r >> 2) & 3))};
             // the epilogue's sixteen activations first (LDS returns in order: they are long there when the products finish), then the A
             // fragments ONE k step ahead of their six MFMAs -- left to the compiler, a step's reads sat right in front of its first MFMA and
             // the lone D wave of a SIMD ate an LDS round trip per step (1200 of its 5400 cycles per block)
@@ -439,12 +467,12 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
             for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
             bf16x8 av[2][3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG);
+            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga2[0] + m * IMG);
 #pragma unroll
             for (int s2 = 0; s2 < CX / 16; ++s2) {
                 if (s2 + 1 < CX / 16) {
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMG + 16 * (s2 + 1));
+                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga2[(s2 + 1) & 1] + m * IMG + 32 * ((s2 + 1) >> 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma6(acc, av[s2 & 1], wf[s2]);
@@ -582,7 +610,7 @@ template <bool GRAM>
 static int launch_x3(const PwBwd &a, hipStream_t st)
 {
     constexpr size_t img = (size_t)32 * 160 * 2;
-    constexpr size_t lds = 2 * 3 * img * (GRAM ? 1 : 2) + (size_t)2 * 32 * 132 * 4;
+    constexpr size_t lds = 2 * 3 * img * (GRAM ? 1 : 2) + (size_t)2 * 32 * 136 * 4;
     static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
     static bool attr_set = false;
     auto kern = pw_bwd_x3_kernel<GRAM>;
@@ -615,7 +643,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 {
     constexpr int CX = 128, CY = 64, ROWS = 32;
     constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 rows of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
-    constexpr int LDZ = CY + 4;                     // fp32 row of the (activated) input tile
+    constexpr int LDZ = CY + 8;                     // fp32 row of the (activated) input tile (4 rows = 32 banks on)
     constexpr int IMGG = ROWS * LDG, IMGY = ROWS * LDY;
     constexpr int NS = 256;                         // staging threads
     constexpr int QX = CX / 4, QY = CY / 4;         // 32 / 16 channel quads
@@ -626,6 +654,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     float *red = reinterpret_cast<float *>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const TrLane trl = tr_lane(LDG, lane);
     const int slot = blockIdx.x % a.n_slots, jb = blockIdx.x / a.n_slots;
     const bool s_role = wave < 2 || wave >= 6, w_role = wave == 2 || wave == 3, d_role = wave == 4 || wave == 5;
     const int stid = ((wave < 2 ? wave : wave - 4) << 6) | lane;       // 0 .. 255 over the four staging waves
@@ -773,9 +802,10 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
             }
             bf16x4 t1, t2, t3;
             split4(xv, t1, t2, t3);
-            *reinterpret_cast<bf16x4 *>(g + lrow * LDG + 4 * cqx) = t1;
-            *reinterpret_cast<bf16x4 *>(g + IMGG + lrow * LDG + 4 * cqx) = t2;
-            *reinterpret_cast<bf16x4 *>(g + 2 * IMGG + lrow * LDG + 4 * cqx) = t3;
+            const int gofs = lrow * LDG + swz_col(lrow, 4 * cqx);
+            *reinterpret_cast<bf16x4 *>(g + gofs) = t1;
+            *reinterpret_cast<bf16x4 *>(g + IMGG + gofs) = t2;
+            *reinterpret_cast<bf16x4 *>(g + 2 * IMGG + gofs) = t3;
         }
 #pragma unroll
         for (int i = 0; i < NIY; ++i) {
@@ -866,7 +896,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand(g + m * IMGG, LDG, 16 * s2, 32 * (2 * wi + i), lane);
+                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand_swz(g + m * IMGG, LDG, 16 * s2, 32 * (2 * wi + i), trl);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -887,15 +917,15 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
             }
-            const __bf16 *ga = g + r * LDG + 8 * h;
+            const __bf16 *ga2[2] = {g + r * LDG + 8 * ((0 + h) ^ ((r >> 2) & 3)), g + r * LDG + 8 * ((2 + h) ^ ((r >> 2) & 3))};     // swizzled row (swz_col)
             bf16x8 av[2][3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMGG);
+            for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga2[0] + m * IMGG);
 #pragma unroll
             for (int s2 = 0; s2 < CX / 16; ++s2) {
                 if (s2 + 1 < CX / 16) {
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga + m * IMGG + 16 * (s2 + 1));
+                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga2[(s2 + 1) & 1] + m * IMGG + 32 * ((s2 + 1) >> 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma6(acc, av[s2 & 1], wf[s2]);
@@ -985,7 +1015,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 template <bool YACT>
 static int launch_x3n(const PwBwd &a, hipStream_t st)
 {
-    constexpr size_t buf = (size_t)3 * 32 * 160 * 2 + (size_t)3 * 32 * 96 * 2 + (size_t)32 * 68 * 4;
+    constexpr size_t buf = (size_t)3 * 32 * 160 * 2 + (size_t)3 * 32 * 96 * 2 + (size_t)32 * 72 * 4;
     constexpr size_t lds = 2 * buf;
     static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
     static bool attr_set = false;
