@@ -421,7 +421,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
                     }
                     mfma6(acc_w[0][0], c0, c0);
                     mfma6(acc_w[0][1], c0, c1);
-                    mfma6(acc_w[1][1], c1, c1);
+                    if (s2 == 0) mfma6(acc_w[1][1], c1, c1);       // the second k step of this diagonal tile belongs to wave ww + 2: 30 MFMAs per wave and block
                 } else {
                     bf16x8 c0[3], c1[3], c2[3];
 #pragma unroll
@@ -432,6 +432,11 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
                     }
                     mfma6(acc_w[0][0], c0, c2);
                     mfma6(acc_w[1][0], c1, c2);
+                    // + the second k step of wave ww - 2's tile (1,1) / (3,3), whose operand this wave holds anyway (merged at the flush)
+                    if (s2 == 1) {
+                        if (ww == 2) mfma6(acc_w[1][1], c1, c1);
+                        else mfma6(acc_w[1][1], c2, c2);
+                    }
                 }
             }
         } else if constexpr (W_ROLE) {
@@ -547,6 +552,20 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3_kernel(PwBwd a)
     if (GRAM && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) g_bx_stamps[threadIdx.x >> 8][0] = (unsigned long long)stamp_n;
 #endif
     // ---- flush: weight-gradient partial of this workgroup, bias sums, BatchNorm-backward sums ----
+    if (GRAM) {
+        // the halves of the two shared diagonal tiles meet: waves 2 / 3 hand theirs to waves 0 / 1 (fixed order: bitwise reproducible);
+        // the staged tiles are consumed, the scratch sits past the bias-sum scratch used below
+        float *xch = reinterpret_cast<float *>(smem_raw) + 4096;       // [2][16][64]
+        if (w_role && ww >= 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xch[((ww - 2) * 16 + e) * 64 + lane] = acc_w[1][1][e];
+        }
+        __syncthreads();
+        if (w_role && ww < 2) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_w[1][1][e] += xch[(ww * 16 + e) * 64 + lane];
+        }
+    }
     if (w_role && GRAM) {
         // the upper-triangle tiles and their mirror images (see the W role above)
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
