@@ -601,6 +601,8 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][e] = init_v[t];
             PW_STAMP(2);                                     // tile begins
+            int wb01 = r * LDB + 8 * h, wb2 = wb01 + 2 * CB * LDB;       // element offsets into sWb (the pointer itself keeps its LDS address space)
+            asm volatile("" : "+v"(wb01), "+v"(wb2));                    // opaque per tile: nothing to hoist out of the loops
 #pragma unroll
             for (int sp = 0; sp < NSTEP; ++sp) {
                 // request step sp + AHEAD (unconditional: behind a branch the wait counts below turn conservative, vmcnt(0) at the tile's end)
@@ -621,9 +623,12 @@ __global__ __launch_bounds__(NW * 64, X3 ? 1 : 2) void pw_gemm_kernel(PwGemm a)
                 bf16x8 a1, a2, a3, b1[NT], b2[NT], b3[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    b1[t] = *reinterpret_cast<const bf16x8 *>(sWb + (32 * t + r) * LDB + k0);
-                    b2[t] = *reinterpret_cast<const bf16x8 *>(sWb + (CB + 32 * t + r) * LDB + k0);
-                    b3[t] = *reinterpret_cast<const bf16x8 *>(sWb + (2 * CB + 32 * t + r) * LDB + k0);
+                    // two lane bases + immediates (the three images span 104 KB, a ds_read offset reaches 64 KB): left to itself the compiler kept
+                    // sixteen address registers for these reads in the kernel that also stores Z, spilled them, and every reload in the k loop
+                    // waited for ALL global loads in flight (scratch reloads count on vmcnt)
+                    b1[t] = *reinterpret_cast<const bf16x8 *>(sWb + wb01 + (32 * t) * LDB + 16 * sp);
+                    b2[t] = *reinterpret_cast<const bf16x8 *>(sWb + wb01 + (CB + 32 * t) * LDB + 16 * sp);
+                    b3[t] = *reinterpret_cast<const bf16x8 *>(sWb + wb2 + (32 * t) * LDB + 16 * sp);
                 }
                 split3_bf16(lo, hi, a1, a2, a3);
                 // six exact partial products per tile; one accumulator takes its six back to back (a dependent chain of this MFMA issues at
