@@ -657,17 +657,22 @@ static int launch_x3(const PwBwd &a, hipStream_t st)
 //     waves 2, 3       (W): dW[cx][cy] += sum_rows g a, four 32 x 32 tiles each (k = rows, transposed LDS reads): 48 MFMAs per block
 //     waves 4, 5       (D): out[row][32 d ..] = mask (g W), weight column block as 8 x 3 bf16 fragments in registers: 48 MFMAs per block
 // A workgroup's waves are dealt to the SIMDs 0, 1, 2, 3, 0, 1, 2, 3: every SIMD holds one MFMA wave and one staging wave.
-template <bool YACT>
+template <int CX, int CY, bool YACT, bool DROP>
 __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 {
-    constexpr int CX = 128, CY = 64, ROWS = 32;
+    static_assert((CX == 128 && CY == 64) || (CX == 64 && CY == 128), "shapes with 48 + 48 MFMAs per block");
+    static_assert(!DROP || YACT, "dropout sits on an activated input");
+    constexpr int ROWS = 32;
     constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 rows of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
     constexpr int LDZ = CY + 8;                     // fp32 row of the (activated) input tile (4 rows = 32 banks on)
     constexpr int IMGG = ROWS * LDG, IMGY = ROWS * LDY;
     constexpr int NS = 256;                         // staging threads
-    constexpr int QX = CX / 4, QY = CY / 4;         // 32 / 16 channel quads
-    constexpr int SX = NS / QX, SY = NS / QY;       // 8 / 16 row groups
-    constexpr int NIX = ROWS / SX, NIY = ROWS / SY; // 4 / 2 quads per staging thread
+    constexpr int QX = CX / 4, QY = CY / 4;         // channel quads per row
+    constexpr int SX = NS / QX, SY = NS / QY;       // row groups
+    constexpr int NIX = ROWS / SX, NIY = ROWS / SY; // quads per staging thread (4 + 2 at 128 x 64, 2 + 4 at 64 x 128)
+    constexpr int FG = X3B_THREADS / QX;            // prologue: groups of channel quads over the whole workgroup
+    constexpr int TXW = CX / 64, TYW = CY / 32;     // W role: x blocks per wave, y blocks (all of them): 4 tiles per wave
+    constexpr int DB = CY / 64, KS = CX / 16;       // D role: column blocks per wave, k steps: DB * KS * 6 = 48 MFMAs per block
     constexpr size_t BUF = (size_t)3 * IMGG * 2 + (size_t)3 * IMGY * 2 + (size_t)ROWS * LDZ * 4;      // bytes of one staged block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *red = reinterpret_cast<float *>(smem_raw);
@@ -688,22 +693,22 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     // ---- BatchNorm-backward constants of the layer g belongs to (formed here from the producer's partial sums, or read) ----
     f32x4 p1 = {1.f, 1.f, 1.f, 1.f}, p2 = {0.f, 0.f, 0.f, 0.f}, p3 = {0.f, 0.f, 0.f, 0.f};
     if (a.fin_part_a) {
-        // every thread takes part (512 = 16 groups of 32 channel quads), pw_bwd_fused.hip: fin_*
+        // every thread takes part (512 = FG groups of QX channel quads), pw_bwd_fused.hip: fin_*
         const int fq = tid % QX, fg = tid / QX;
         double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
         const int per_slot_parts = (a.fin_parts - slot + a.n_slots - 1) / a.n_slots;
-        for (int k0 = fg; k0 < per_slot_parts; k0 += 16 * 8) {
+        for (int k0 = fg; k0 < per_slot_parts; k0 += FG * 8) {
             f32x4 va[8], vb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int k = k0 + 16 * u;
+                const int k = k0 + FG * u;
                 const size_t o = (size_t)(slot + (k < per_slot_parts ? k : 0) * a.n_slots) * CX + 4 * fq;
                 va[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_a + o);
                 vb[u] = *reinterpret_cast<const f32x4 *>(a.fin_part_b + o);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (k0 + 16 * u < per_slot_parts) {
+                if (k0 + FG * u < per_slot_parts) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         sa[c] += (double)va[u][c];
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
                 }
             }
         }
-        double *redd = reinterpret_cast<double *>(smem_raw);          // [16][CX][2] = 32 KB: the staging buffers are not in use yet
+        double *redd = reinterpret_cast<double *>(smem_raw);          // [FG][CX][2] = 32 KB: the staging buffers are not in use yet
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             redd[((size_t)fg * CX + 4 * fq + c) * 2 + 0] = sa[c];
@@ -725,7 +730,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
         for (int c = 0; c < 4; ++c) {
             const int ch = 4 * cqx + c;
             double A = 0.0, Bs = 0.0;
-            for (int gq = 0; gq < 16; ++gq) {
+            for (int gq = 0; gq < FG; ++gq) {
                 A += redd[((size_t)gq * CX + ch) * 2 + 0];
                 Bs += redd[((size_t)gq * CX + ch) * 2 + 1];
             }
@@ -804,6 +809,8 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     };
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
     const bool want_db = a.dbpart != nullptr;
+    const uint32_t dthr = drop_threshold(a.prev.drop_p);
+    const float dscale = DROP ? 1.0f / (1.0f - a.prev.drop_p) : 1.0f;
     auto write_lds = [&](int buf_, const Pos &p, const Regs &R) {
         int bsel = buf_;
         asm volatile("" : "+s"(bsel));               // keeps the addresses of the two buffers from being hoisted apart (see pw_bwd_x3_kernel)
@@ -833,6 +840,11 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
             if (YACT) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) yv[c] = fmaxf(fmaf(yv[c], ys[c], yt[c]), 0.f);
+                if (DROP) {                  // the layer's input went through dropout: one hash per staged element (pw_bwd_fused.hip)
+                    const uint32_t e0 = (uint32_t)row * (uint32_t)CY + (uint32_t)(4 * cqy);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) yv[c] = (mix32((e0 + c) ^ a.prev.drop_seed) >= dthr) ? yv[c] * dscale : 0.f;
+                }
                 *reinterpret_cast<f32x4 *>(z + lrow * LDZ + 4 * cqy) = yv;           // (finite filler on rows past the end: masked in the epilogue)
             }
             if (!(row < p.row_end)) yv = f32x4{0.f, 0.f, 0.f, 0.f};               // rows past the block's end contribute nothing to dW
@@ -845,35 +857,33 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     };
 
     // ---- role state ----
-    const int wi = wave & 1;                               // W: column blocks 2 wi, 2 wi + 1 of cx;  D: column block wi of cy
-    f32x16 acc_w[2][2];
+    const int wi = wave & 1;                               // W: x blocks TXW wi .. of cx, every y block;  D: column blocks DB wi .. of cy
+    f32x16 acc_w[TXW][TYW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TXW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TYW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc_w[i][j][e] = 0.f;
-    const int dcol = 32 * wi + r;
-    bf16x8 wf[CX / 16][3];
-    if (d_role) {
-        const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+    int dcol[DB];
+    bf16x8 wf[DB][KS][3];                                  // the wave's column blocks of the weight: 96 VGPRs at either shape
+    float c_b[DB], c_beta[DB], c_invg[DB];
 #pragma unroll
-        for (int s2 = 0; s2 < CX / 16; ++s2) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol];
-            split8(v, wf[s2][0], wf[s2][1], wf[s2][2]);
-        }
+    for (int bq = 0; bq < DB; ++bq) {
+        dcol[bq] = 32 * (DB * wi + bq) + r;
+        c_b[bq] = a.bias_slot ? a.bias_slot[(size_t)slot * CY + dcol[bq]] : 0.f;
+        const float c_s = YACT ? a.prev.s[(size_t)slot * CY + dcol[bq]] : 1.0f;
+        const float c_t = YACT ? a.prev.t[(size_t)slot * CY + dcol[bq]] : 0.0f;
+        const float c_m = (YACT && a.prev_mean) ? a.prev_mean[(size_t)slot * CY + dcol[bq]] : 0.0f;
+        const float c_i = (YACT && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol[bq]] : 0.0f;
+        c_beta[bq] = fmaf(c_m, c_s, c_t);
+        c_invg[bq] = c_s != 0.f ? c_i / c_s : 0.f;
     }
-    const float c_b = a.bias_slot ? a.bias_slot[(size_t)slot * CY + dcol] : 0.f;
-    const float c_s = YACT ? a.prev.s[(size_t)slot * CY + dcol] : 1.0f;
-    const float c_t = YACT ? a.prev.t[(size_t)slot * CY + dcol] : 0.0f;
-    const float c_m = (YACT && a.prev_mean) ? a.prev_mean[(size_t)slot * CY + dcol] : 0.0f;
-    const float c_i = (YACT && a.prev_invstd) ? a.prev_invstd[(size_t)slot * CY + dcol] : 0.0f;
-    const float c_beta = fmaf(c_m, c_s, c_t);
-    const float c_invg = c_s != 0.f ? c_i / c_s : 0.f;
+    const float c_undrop = DROP ? 1.0f - a.prev.drop_p : 1.0f;      // a = a' (1 - p) for a kept element
     const bool do_part = a.part_a != nullptr;
-    float s_a = 0.f, s_b = 0.f;
+    float s_a[DB], s_b[DB];
+#pragma unroll
+    for (int bq = 0; bq < DB; ++bq) s_a[bq] = s_b[bq] = 0.f;
 
     // blocks n (in LDS), n + 1 and n + 2 (in the stagers' two register sets); a tail position repeats the last real one (unconditional loads)
     Pos cur, nxt, nx2;
@@ -911,64 +921,89 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
         } else if constexpr (ROLE == 1) {
 #pragma unroll
             for (int s2 = 0; s2 < ROWS / 16; ++s2) {
-                bf16x8 xa[2][3], yb[2][3];
+                bf16x8 xa[TXW][3], yb[TYW][3];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TXW; ++i)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand_swz(g + m * IMGG, LDG, 16 * s2, 32 * (2 * wi + i), trl);
+                    for (int m = 0; m < 3; ++m) xa[i][m] = tr_operand_swz(g + m * IMGG, LDG, 16 * s2, 32 * (TXW * wi + i), trl);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TYW; ++j)
 #pragma unroll
                     for (int m = 0; m < 3; ++m) yb[j][m] = tr_operand(y + m * IMGY, LDY, 16 * s2, 32 * j, lane);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TXW; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mfma6(acc_w[i][j], xa[i], yb[j]);
+                    for (int j = 0; j < TYW; ++j) mfma6(acc_w[i][j], xa[i], yb[j]);
             }
         } else {
             const int valid = min(ROWS, cur.row_end - cur.row0);
             const int trow0 = cur.row0;
-            f32x16 acc;
+            f32x16 acc[DB];
+            // one column block: the sixteen activations of its epilogue are requested up front (LDS returns in order: long there when the products
+            // finish); two: after the products, the second block's under the first block's epilogue
+            float zv[2][16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = c_b;
-            float zv[16];
-            if (YACT) {
+            for (int bq = 0; bq < DB; ++bq) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) zv[e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol];
+                for (int e = 0; e < 16; ++e) acc[bq][e] = c_b[bq];
+            }
+            if (YACT && DB == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) zv[0][e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol[0]];
             }
             const __bf16 *ga2[2] = {g + r * LDG + 8 * ((0 + h) ^ ((r >> 2) & 3)), g + r * LDG + 8 * ((2 + h) ^ ((r >> 2) & 3))};     // swizzled row (swz_col)
-            bf16x8 av[2][3];
+            // A fragments one k step ahead of their MFMAs (two register sets) when one column block leaves room for them; with two column
+            // blocks (12 MFMAs per step cover most of an LDS round trip, and 24 more VGPRs would spill into this loop) one set, read per step
+            constexpr int AVS = DB == 1 ? 2 : 1;
+            bf16x8 av[AVS][3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga2[0] + m * IMGG);
 #pragma unroll
-            for (int s2 = 0; s2 < CX / 16; ++s2) {
-                if (s2 + 1 < CX / 16) {
+            for (int s2 = 0; s2 < KS; ++s2) {
+                if (AVS == 2 && s2 + 1 < KS) {
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) av[(s2 + 1) & 1][m] = *reinterpret_cast<const bf16x8 *>(ga2[(s2 + 1) & 1] + m * IMGG + 32 * ((s2 + 1) >> 1));
+                    for (int m = 0; m < 3; ++m) av[(s2 + 1) % AVS][m] = *reinterpret_cast<const bf16x8 *>(ga2[(s2 + 1) & 1] + m * IMGG + 32 * ((s2 + 1) >> 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mfma6(acc, av[s2 & 1], wf[s2]);
+#pragma unroll
+                for (int bq = 0; bq < DB; ++bq) mfma6(acc[bq], av[s2 % AVS], wf[bq][s2]);
+                if (AVS == 1 && s2 + 1 < KS) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const bf16x8 *>(ga2[(s2 + 1) & 1] + m * IMGG + 32 * ((s2 + 1) >> 1));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol;
-            auto finish = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;
+            if (YACT && DB > 1) {             // two column blocks: no room for the activations next to 96 weight VGPRs + two accumulators during the products
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const bool ok = FULL || rr < valid;
-                    float v = acc[e];
-                    if (YACT) {
-                        v = zv[e] > 0.f ? v : 0.f;                           // ReLU mask of the layer's input: a > 0
-                        const float vs = ok ? v : 0.f;
-                        s_a += vs;
-                        s_b = fmaf(vs, (zv[e] - c_beta) * c_invg, s_b);      // zhat = (a - beta) / gamma where the mask holds
-                    }
-                    if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
+                for (int e = 0; e < 16; ++e) zv[0][e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol[0]];
+            }
+#pragma unroll
+            for (int bq = 0; bq < DB; ++bq) {
+                if (YACT && bq + 1 < DB) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) zv[(bq + 1) & 1][e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol[bq + 1]];
                 }
-            };
-            if (valid >= 32) finish(std::true_type{});
-            else finish(std::false_type{});
+                float *op = a.out + (size_t)(trow0 + 4 * h) * CY + dcol[bq];
+                auto finish = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = FULL || rr < valid;
+                        float v = acc[bq][e];
+                        if (YACT) {
+                            if (DROP) v *= dscale;                               // kept elements only survive the mask below
+                            v = zv[bq & 1][e] > 0.f ? v : 0.f;                   // ReLU (and dropout) mask of the layer's input: a > 0
+                            const float vs = ok ? v : 0.f;
+                            s_a[bq] += vs;
+                            s_b[bq] = fmaf(vs, (zv[bq & 1][e] * c_undrop - c_beta[bq]) * c_invg[bq], s_b[bq]);      // zhat = (a - beta) / gamma where the mask holds
+                        }
+                        if (ok) st_stream(v, &op[((e & 3) + 8 * (e >> 2)) * CY]);
+                    }
+                };
+                if (valid >= 32) finish(std::true_type{});
+                else finish(std::false_type{});
+            }
         }
         __syncthreads();
         buf ^= 1;
@@ -988,6 +1023,18 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     } else if (w_role) {
         while (live) step(S0, std::integral_constant<int, 1>{});
     } else {
+        // the weight fragments are fetched HERE, after the staging waves' priming block above: loaded before it they were live across it
+        // (96 VGPRs next to two staging register sets) and the allocator spilled one of them into this loop
+        const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+#pragma unroll
+        for (int bq = 0; bq < DB; ++bq)
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol[bq]];
+                split8(v, wf[bq][s2][0], wf[bq][s2][1], wf[bq][s2][2]);
+            }
         while (live) step(S0, std::integral_constant<int, 2>{});
     }
 
@@ -995,13 +1042,13 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     if (w_role) {
         float *dst = a.dWpart + (size_t)blockIdx.x * CX * CY;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TXW; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TYW; ++j) {
                 const int cy = 32 * j + r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int cx = 32 * (2 * wi + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int cx = 32 * (TXW * wi + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
                     dst[(size_t)cx * CY + cy] = acc_w[i][j][e];
                 }
             }
@@ -1018,10 +1065,13 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
         __syncthreads();
     }
     if (do_part) {
-        const float oa = __shfl_xor(s_a, 32), ob = __shfl_xor(s_b, 32);
-        if (d_role && h == 0) {
-            red[dcol * 2 + 0] = s_a + oa;
-            red[dcol * 2 + 1] = s_b + ob;
+#pragma unroll
+        for (int bq = 0; bq < DB; ++bq) {
+            const float oa = __shfl_xor(s_a[bq], 32), ob = __shfl_xor(s_b[bq], 32);
+            if (d_role && h == 0) {
+                red[dcol[bq] * 2 + 0] = s_a[bq] + oa;
+                red[dcol[bq] * 2 + 1] = s_b[bq] + ob;
+            }
         }
         __syncthreads();
         if (tid < CY) {
@@ -1031,23 +1081,23 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     }
 }
 
-template <bool YACT>
+template <int CX, int CY, bool YACT, bool DROP>
 static int launch_x3n(const PwBwd &a, hipStream_t st)
 {
-    constexpr size_t buf = (size_t)3 * 32 * 160 * 2 + (size_t)3 * 32 * 96 * 2 + (size_t)32 * 72 * 4;
+    constexpr size_t buf = (size_t)3 * 32 * (CX + 32) * 2 + (size_t)3 * 32 * (CY + 32) * 2 + (size_t)32 * (CY + 8) * 4;
     constexpr size_t lds = 2 * buf;
     static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
     static bool attr_set = false;
-    auto kern = pw_bwd_x3n_kernel<YACT>;
+    auto kern = pw_bwd_x3n_kernel<CX, CY, YACT, DROP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_x3n: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
     char name[64];
-    snprintf(name, sizeof(name), "pw_bwd<128,64>%s x3", YACT ? "" : " lin");
+    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s%s x3", CX, CY, YACT ? "" : " lin", DROP ? "+drop" : "");
     const double rows = (double)a.rows_hint;
-    ProfScope prof(name, 4.0 * rows * 128 * 64, rows * 4.0 * (128 + 128 + 64 + 64), st);
+    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * (2 * CX + 2 * CY), st);
     hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(X3B_THREADS), lds, st, a);
     return check_launch("pw_bwd_x3n_kernel");
 }
@@ -1056,9 +1106,13 @@ static int launch_x3n(const PwBwd &a, hipStream_t st)
 bool pw_bwd_x3_supported(const PwBwd &a)
 {
     const bool gram = a.g.act != 0;
-    if (a.add || a.prev.drop_p > 0.f || a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
+    if (a.add || a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
+    const bool dense_g = !gram && a.g.dy != nullptr && a.g.z != nullptr && (a.g.P1 != nullptr || a.fin_part_a != nullptr);
+    // 64 -> 128 (the head's conv_3: its input is an activation that went through dropout)
+    if (a.g.C == 64 && a.prev.C == 128) return dense_g && a.prev.s != nullptr && a.prev.drop_p < 1.f;
+    if (a.prev.drop_p > 0.f) return false;
     if (a.g.C == 128 && a.prev.C == 128) return a.prev.s != nullptr && (gram ? a.g.z == a.prev.z : (a.g.dy != nullptr));
-    if (a.g.C == 128 && a.prev.C == 64) return !gram && a.g.dy != nullptr && a.g.z != nullptr && (a.g.P1 != nullptr || a.fin_part_a != nullptr);
+    if (a.g.C == 128 && a.prev.C == 64) return dense_g;
     return false;
 }
 
@@ -1067,7 +1121,8 @@ int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st)
 {
     static_assert(X3B_ITEM_ROWS == 256, "item size shared with pw_bwd_fused.hip");
     AMPNET_REQUIRE(pw_bwd_x3_supported(a), "pw_bwd_x3: shape not built");
-    if (a.prev.C == 64) return a.prev.s ? launch_x3n<true>(a, st) : launch_x3n<false>(a, st);
+    if (a.g.C == 64) return a.prev.drop_p > 0.f ? launch_x3n<64, 128, true, true>(a, st) : launch_x3n<64, 128, true, false>(a, st);
+    if (a.prev.C == 64) return a.prev.s ? launch_x3n<128, 64, true, false>(a, st) : launch_x3n<128, 64, false, false>(a, st);
     return a.g.act ? launch_x3<true>(a, st) : launch_x3<false>(a, st);
 }
 
