@@ -657,10 +657,11 @@ static int launch_x3(const PwBwd &a, hipStream_t st)
 //     waves 2, 3       (W): dW[cx][cy] += sum_rows g a, four 32 x 32 tiles each (k = rows, transposed LDS reads): 48 MFMAs per block
 //     waves 4, 5       (D): out[row][32 d ..] = mask (g W), weight column block as 8 x 3 bf16 fragments in registers: 48 MFMAs per block
 // A workgroup's waves are dealt to the SIMDs 0, 1, 2, 3, 0, 1, 2, 3: every SIMD holds one MFMA wave and one staging wave.
-template <int CX, int CY, bool YACT, bool DROP>
+template <int CX, int CY, bool YACT, bool DROP, bool ADD>
 __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 {
-    static_assert((CX == 128 && CY == 64) || (CX == 64 && CY == 128), "shapes with 48 + 48 MFMAs per block");
+    static_assert((CX == 128 && CY == 64) || (CX == 64 && CY == 128) || (CX == 64 && CY == 64), "48 + 48 MFMAs per block (24 + 24 at 64 x 64: HBM-bound)");
+    static_assert(!ADD || (CX == 64 && CY == 64), "the addend exists on the 64 x 64 launches");
     static_assert(!DROP || YACT, "dropout sits on an activated input");
     constexpr int ROWS = 32;
     constexpr int LDG = CX + 32, LDY = CY + 32;     // bf16 rows of the operand tiles (2 C + 64 bytes: transposed reads conflict-free)
@@ -951,6 +952,14 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) zv[0][e] = z[((e & 3) + 8 * (e >> 2) + 4 * h) * LDZ + dcol[0]];
             }
+            float addv[16];                       // ADD: the gradient that joins this layer's input from another branch (DB == 1 there)
+            if (ADD) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    addv[e] = rr < valid ? ld_stream(&a.add[(size_t)(trow0 + rr) * CY + dcol[0]]) : 0.f;
+                }
+            }
             const __bf16 *ga2[2] = {g + r * LDG + 8 * ((0 + h) ^ ((r >> 2) & 3)), g + r * LDG + 8 * ((2 + h) ^ ((r >> 2) & 3))};     // swizzled row (swz_col)
             // A fragments one k step ahead of their MFMAs (two register sets) when one column block leaves room for them; with two column
             // blocks (12 MFMAs per step cover most of an LDS round trip, and 24 more VGPRs would spill into this loop) one set, read per step
@@ -991,6 +1000,7 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
                         const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
                         const bool ok = FULL || rr < valid;
                         float v = acc[bq][e];
+                        if (ADD) v += addv[e];
                         if (YACT) {
                             if (DROP) v *= dscale;                               // kept elements only survive the mask below
                             v = zv[bq & 1][e] > 0.f ? v : 0.f;                   // ReLU (and dropout) mask of the layer's input: a > 0
@@ -1081,23 +1091,23 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
     }
 }
 
-template <int CX, int CY, bool YACT, bool DROP>
+template <int CX, int CY, bool YACT, bool DROP, bool ADD = false>
 static int launch_x3n(const PwBwd &a, hipStream_t st)
 {
     constexpr size_t buf = (size_t)3 * 32 * (CX + 32) * 2 + (size_t)3 * 32 * (CY + 32) * 2 + (size_t)32 * (CY + 8) * 4;
     constexpr size_t lds = 2 * buf;
     static_assert(lds <= 160 * 1024 && lds >= (size_t)16 * 128 * 2 * 8, "LDS budget (tiles; the prologue's double scratch aliases them)");
     static bool attr_set = false;
-    auto kern = pw_bwd_x3n_kernel<CX, CY, YACT, DROP>;
+    auto kern = pw_bwd_x3n_kernel<CX, CY, YACT, DROP, ADD>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(AMPNET_E_LAUNCH, "pw_bwd_x3n: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
         attr_set = true;
     }
     char name[64];
-    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s%s x3", CX, CY, YACT ? "" : " lin", DROP ? "+drop" : "");
+    snprintf(name, sizeof(name), "pw_bwd<%d,%d>%s%s%s x3", CX, CY, YACT ? "" : " lin", ADD ? "+add" : "", DROP ? "+drop" : "");
     const double rows = (double)a.rows_hint;
-    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * (2 * CX + 2 * CY), st);
+    ProfScope prof(name, 4.0 * rows * CX * CY, rows * 4.0 * (2 * CX + 2 * CY + (ADD ? CY : 0)), st);
     hipLaunchKernelGGL(kern, dim3(a.blocks_per_slot * a.n_slots), dim3(X3B_THREADS), lds, st, a);
     return check_launch("pw_bwd_x3n_kernel");
 }
@@ -1106,8 +1116,11 @@ static int launch_x3n(const PwBwd &a, hipStream_t st)
 bool pw_bwd_x3_supported(const PwBwd &a)
 {
     const bool gram = a.g.act != 0;
-    if (a.add || a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
+    if (a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
     const bool dense_g = !gram && a.g.dy != nullptr && a.g.z != nullptr && (a.g.P1 != nullptr || a.fin_part_a != nullptr);
+    // 64 -> 64 (conv_2 / conv_3 of the encoder and the feature T-Net's conv_1; some with the addend of a joining branch): the built variants
+    if (a.g.C == 64 && a.prev.C == 64) return dense_g && !(a.prev.drop_p > 0.f) && (a.prev.s != nullptr || a.add != nullptr);
+    if (a.add) return false;
     // 64 -> 128 (the head's conv_3: its input is an activation that went through dropout)
     if (a.g.C == 64 && a.prev.C == 128) return dense_g && a.prev.s != nullptr && a.prev.drop_p < 1.f;
     if (a.prev.drop_p > 0.f) return false;
@@ -1121,6 +1134,10 @@ int pw_bwd_fused_x3(const PwBwd &a, hipStream_t st)
 {
     static_assert(X3B_ITEM_ROWS == 256, "item size shared with pw_bwd_fused.hip");
     AMPNET_REQUIRE(pw_bwd_x3_supported(a), "pw_bwd_x3: shape not built");
+    if (a.g.C == 64 && a.prev.C == 64) {
+        if (a.prev.s) return a.add ? launch_x3n<64, 64, true, false, true>(a, st) : launch_x3n<64, 64, true, false, false>(a, st);
+        return launch_x3n<64, 64, false, false, true>(a, st);
+    }
     if (a.g.C == 64) return a.prev.drop_p > 0.f ? launch_x3n<64, 128, true, true>(a, st) : launch_x3n<64, 128, true, false>(a, st);
     if (a.prev.C == 64) return a.prev.s ? launch_x3n<128, 64, true, false>(a, st) : launch_x3n<128, 64, false, false>(a, st);
     return a.g.act ? launch_x3<true>(a, st) : launch_x3<false>(a, st);

@@ -52,9 +52,10 @@ def main(src, dst, rows_per_launch=64 * 9 * 2048, fps_src=None, fps_cases=None):
         if m:
             x3 = re.match(r"ampnet::pw_gemm_kernel<(?:[^,]+, ){9}true", sym) is not None                    # the three-term split kernels (mode f32x3)
             name = f"pw_gemm<{m.group(1)},{32 * int(m.group(2))}>" + ("+pool" if m.group(4) == "true" else "+store") + (" x3" if x3 else (" bf16" if m.group(5) == "true" else ""))
-        m = re.match(r"ampnet::pw_bwd_x3n_kernel<(\d+), (\d+), (true|false), (true|false)>", sym)
+        m = re.match(r"ampnet::pw_bwd_x3n_kernel<(\d+), (\d+), (true|false), (true|false), (true|false)>", sym)
         if m:
-            name = f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("" if m.group(3) == "true" else " lin") + ("+drop" if m.group(4) == "true" else "") + " x3"
+            name = (f"pw_bwd<{m.group(1)},{m.group(2)}>" + ("" if m.group(3) == "true" else " lin") + ("+add" if m.group(5) == "true" else "")
+                    + ("+drop" if m.group(4) == "true" else "") + " x3")
         m = re.match(r"ampnet::pw_bwd_x3_kernel<(true|false)>", sym)
         if m:
             name = "pw_bwd<128,128>" + ("+gram" if m.group(1) == "true" else "") + " x3"
