@@ -1036,13 +1036,22 @@ __global__ __launch_bounds__(X3B_THREADS, 1) void pw_bwd_x3n_kernel(PwBwd a)
         // the weight fragments are fetched HERE, after the staging waves' priming block above: loaded before it they were live across it
         // (96 VGPRs next to two staging register sets) and the allocator spilled one of them into this loop
         const float *Wsh = a.W + (size_t)slot * a.w_slot_stride;
+        const float *Tq = nullptr;
+        if (a.w_win_stride != 0) {
+            // per-window matrix T[pidx][cy][cx] (the bmm transform: out[row][cy] = sum_cx g[row][cx] T[cy][cx]); the host keeps every workgroup
+            // inside one window (pw_bwd_fused.hip)
+            const int bi = item_begin / cpw;
+            const int pidx = a.perwin_slot_major ? slot * (a.Q / a.n_slots) + bi : bi * a.n_slots + slot;
+            Tq = a.W + (size_t)pidx * a.w_win_stride;
+        }
 #pragma unroll
         for (int bq = 0; bq < DB; ++bq)
 #pragma unroll
             for (int s2 = 0; s2 < KS; ++s2) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol[bq]];
+                for (int j = 0; j < 8; ++j)
+                    v[j] = Tq ? Tq[(size_t)dcol[bq] * CX + 16 * s2 + 8 * h + j] : Wsh[(size_t)(16 * s2 + 8 * h + j) * a.ldw + dcol[bq]];
                 split8(v, wf[bq][s2][0], wf[bq][s2][1], wf[bq][s2][2]);
             }
         while (live) step(S0, std::integral_constant<int, 2>{});
@@ -1116,7 +1125,8 @@ static int launch_x3n(const PwBwd &a, hipStream_t st)
 bool pw_bwd_x3_supported(const PwBwd &a)
 {
     const bool gram = a.g.act != 0;
-    if (a.w_win_stride || a.g.z_bf16 || a.prev.z_bf16) return false;
+    if (a.g.z_bf16 || a.prev.z_bf16) return false;
+    if (a.w_win_stride && !(a.g.C == 64 && a.prev.C == 64 && a.items_per_block > 0)) return false;      // per-window weights: the bmm backward only
     const bool dense_g = !gram && a.g.dy != nullptr && a.g.z != nullptr && (a.g.P1 != nullptr || a.fin_part_a != nullptr);
     // 64 -> 64 (conv_2 / conv_3 of the encoder and the feature T-Net's conv_1; some with the addend of a joining branch): the built variants
     if (a.g.C == 64 && a.prev.C == 64) return dense_g && !(a.prev.drop_p > 0.f) && (a.prev.s != nullptr || a.add != nullptr);
